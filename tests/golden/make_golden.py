@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the reference's own code (runs ONLY in the build container).
+
+The reference's hot path (`models/layers.py`, `models/flows.py`, `models/kd_flows.py`,
+`models/utils.py`) is imported from /root/reference under a stub parent package, because
+`models/__init__.py:4` imports torchvision (absent).  Nothing of the reference is copied:
+the outputs below are *data* -- inputs, parameters and the tensors the reference computed.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+`pl_module.py` cannot be imported (pytorch_lightning/hydra/neptune absent), so the
+distillation-step case drives the reference *models* with torch's own Adam and
+clip_grad_norm_ following pl_module.py:198-320,350-354 and train.py:46.
+"""
+import importlib
+import json
+import math
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from param_util import randomize_state_dict, shapes_of, synthetic_images  # noqa: E402
+
+REF = "/root/reference/models"
+
+
+def import_reference():
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [REF]
+    sys.modules["models"] = pkg
+    layers = importlib.import_module("models.layers")
+    flows = importlib.import_module("models.flows")
+    kd = importlib.import_module("models.kd_flows")
+    return layers, flows, kd
+
+
+layers, flows, kd = import_reference()
+
+
+def base_cfg(**kw):
+    cfg = dict(image_shape=[8, 8, 3], hidden_channels=16, K=2, L=2, actnorm_scale=1.0,
+               flow_permutation="invconv", flow_coupling="affine", LU_decomposed=True,
+               y_classes=10, learn_top=False, y_condition=False, is_1d=False)
+    cfg.update(kw)
+    return cfg
+
+
+def build(cfg, seed):
+    torch.manual_seed(1234)
+    model = kd.create_glow_model(dict(cfg))
+    sd = randomize_state_dict(shapes_of(model.state_dict()), seed)
+    model.load_state_dict(sd)
+    return model, sd
+
+
+def perms_of(model):
+    out = {}
+    for i, layer in enumerate(model.flow.layers):
+        for name in ("shuffle", "reverse"):
+            if isinstance(getattr(layer, name, None), layers.Permute2d):
+                out[i] = getattr(layer, name).indices.clone()
+    return out
+
+
+def save(name, cfg, arrays):
+    arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+              for k, v in arrays.items()}
+    arrays["cfg"] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def model_case(name, cfg, batch, seed, noise_seed=99):
+    model, sd = build(cfg, seed)
+    is_1d = cfg["is_1d"]
+    g = torch.Generator().manual_seed(seed + 17)
+    arrays = {f"sd/{k}": v for k, v in sd.items()}
+    y = None
+    if cfg["y_condition"]:
+        y = torch.zeros(batch, cfg["y_classes"])
+        y[torch.arange(batch), torch.randint(0, cfg["y_classes"], (batch,), generator=g)] = 1.0
+        arrays["y"] = y
+    if is_1d:
+        x = torch.randn(batch, cfg["image_shape"][0], generator=g)
+        arrays["x"] = x.clone()
+    else:
+        h, w, c = cfg["image_shape"]
+        x, _ = synthetic_images(batch, (c, h, w), seed=seed + 5)
+        arrays["x"] = x.clone()
+        torch.manual_seed(noise_seed)
+        noise = torch.zeros_like(x).uniform_(0, 1.0 / 256)
+        arrays["noise"] = noise
+        torch.manual_seed(noise_seed)  # the reference now draws the same noise
+    for i, t in perms_of(model).items():
+        arrays[f"perm/{i}"] = t
+    model.train()
+    x_in = x.clone()
+    outs, bpd, y_logits = model(x_in, y)
+    if not is_1d:
+        assert torch.equal(x_in, arrays["x"] + arrays["noise"]), "noise replay mismatch"
+    loss = bpd.mean() + (0.1 * (y_logits ** 2).sum() if y_logits is not None else 0.0)
+    loss.backward()
+    for i, o in enumerate(outs):
+        arrays[f"out/{i}"] = o
+    arrays["bpd"] = bpd
+    if y_logits is not None:
+        arrays["y_logits"] = y_logits
+    for k, p in model.named_parameters():
+        arrays[f"grad/{k}"] = p.grad if p.grad is not None else torch.zeros_like(p)
+    # reverse pass from the top latent, temperature 0 (Split2d then returns its mean:
+    # torch.normal(mean, 0) == mean), so no RNG is involved.
+    with torch.no_grad():
+        rev = model(z=outs[-1].detach(), y_onehot=y, temperature=0.0, reverse=True)
+        for i, o in enumerate(rev):
+            arrays[f"rev/{i}"] = o
+        mean, logs = model.prior(outs[-1], y)
+        arrays["prior_mean"], arrays["prior_logs"] = mean, logs
+    # fp64 run of the same reference code: error budget for the fp32 comparison
+    m64, _ = build(cfg, seed)
+    m64 = m64.double()
+    with torch.no_grad():
+        xin64 = (arrays["x"] + arrays["noise"]).double() if not is_1d else arrays["x"].double()
+        ld0 = (torch.zeros(batch, dtype=torch.float64) if is_1d else
+               torch.full((batch,), -math.log(256.0) * xin64[0].numel(), dtype=torch.float64))
+        o64, obj64 = m64.flow(xin64, y_onehot=None if y is None else y.double(), logdet=ld0,
+                              reverse=False)
+        arrays["logdet64"] = obj64
+        arrays["last64"] = o64[-1]
+    save(name, cfg, arrays)
+
+
+def primitive_case():
+    """Per-primitive vectors."""
+    g = torch.Generator().manual_seed(3)
+    arrays = {}
+    x = torch.randn(2, 3, 4, 6, generator=g)
+    arrays["squeeze/x"] = x
+    arrays["squeeze/y"] = layers.squeeze2d(x, 2)
+    arrays["unsqueeze/y"] = layers.unsqueeze2d(layers.squeeze2d(x, 2), 2)
+    mean, logs, z = (torch.randn(3, 4, 2, 2, generator=g) for _ in range(3))
+    arrays["gauss/mean"], arrays["gauss/logs"], arrays["gauss/x"] = mean, logs * 0.3, z
+    arrays["gauss/lp"] = layers.gaussian_likelihood(mean, logs * 0.3, z)
+    for tag, is_1d, shape in (("an2d", False, (3, 6, 4, 4)), ("an1d", True, (5, 7))):
+        c = shape[1]
+        an = (layers.ActNorm1d if is_1d else layers.ActNorm2d)(c)
+        an.inited = True
+        an.bias.data = torch.randn_like(an.bias) * 0.3
+        an.logs.data = torch.randn_like(an.logs) * 0.3
+        xx = torch.randn(*shape, generator=g)
+        ld = torch.randn(shape[0], generator=g)
+        y, ldo = an(xx, ld, reverse=False)
+        yi, ldi = an(xx, ld, reverse=True)
+        arrays.update({f"{tag}/bias": an.bias.data, f"{tag}/logs": an.logs.data, f"{tag}/x": xx,
+                       f"{tag}/ld": ld, f"{tag}/y": y, f"{tag}/ldo": ldo, f"{tag}/yi": yi,
+                       f"{tag}/ldi": ldi})
+    for tag, is_1d, lu, shape in (("ic2d", False, True, (2, 8, 3, 3)),
+                                  ("ic1d", True, True, (4, 7)),
+                                  ("ic2d_nolu", False, False, (2, 6, 2, 2))):
+        c = shape[1]
+        torch.manual_seed(11)
+        ic = layers.InvertibleConv1x1(c, LU_decomposed=lu, is_1d=is_1d)
+        sd = randomize_state_dict({f"invconv.{k}": v.shape for k, v in ic.state_dict().items()}, 21)
+        ic.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items()})
+        xx = torch.randn(*shape, generator=g)
+        ld = torch.randn(shape[0], generator=g)
+        y, ldo = ic(xx, ld, reverse=False)
+        yi, ldi = ic(xx, ld, reverse=True)
+        for k, v in sd.items():
+            arrays[f"{tag}/sd/{k}"] = v
+        arrays.update({f"{tag}/x": xx, f"{tag}/ld": ld, f"{tag}/y": y, f"{tag}/ldo": ldo,
+                       f"{tag}/yi": yi, f"{tag}/ldi": ldi})
+    # Split2d forward and reverse at temperature 0
+    sp = layers.Split2d(8)
+    sd = randomize_state_dict({f"conv.{k}": v.shape for k, v in sp.conv.state_dict().items()}, 31)
+    sp.conv.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items()})
+    xx = torch.randn(2, 8, 4, 4, generator=g)
+    ld = torch.randn(2, generator=g)
+    z1, ldo = sp(xx, ld, reverse=False)
+    zr, _ = sp(z1, 0.0, reverse=True, temperature=0.0)
+    for k, v in sd.items():
+        arrays[f"split/sd/{k}"] = v
+    arrays.update({"split/x": xx, "split/ld": ld, "split/z1": z1, "split/ldo": ldo, "split/rev": zr})
+    save("primitives", {}, arrays)
+
+
+def distill_case():
+    """Two optimisation steps of the distillation training_step on a tiny model pair."""
+    s_cfg = base_cfg(K=1, hidden_channels=16)
+    t_cfg = base_cfg(K=2, hidden_channels=16)
+    student, s_sd = build(s_cfg, 41)
+    teacher, t_sd = build(t_cfg, 43)
+    teacher.eval()
+    s_idx = [i for i, l in enumerate(student.flow.layers)
+             if isinstance(l, layers.SqueezeLayer) or i + 1 == len(student.flow.layers)]
+    t_idx = [i for i, l in enumerate(teacher.flow.layers)
+             if isinstance(l, layers.SqueezeLayer) or i + 1 == len(teacher.flow.layers)]
+    opt = torch.optim.Adam(student.parameters(), lr=5e-4, weight_decay=0)
+    arrays = {f"s_sd/{k}": v for k, v in s_sd.items()}
+    arrays.update({f"t_sd/{k}": v for k, v in t_sd.items()})
+    arrays["s_idx"], arrays["t_idx"] = np.array(s_idx), np.array(t_idx)
+    for step in range(2):
+        x, _ = synthetic_images(4, (3, 8, 8), seed=50 + step)
+        arrays[f"step{step}/x"] = x.clone()
+        torch.manual_seed(70 + step)
+        n_s = torch.zeros_like(x).uniform_(0, 1.0 / 256)
+        n_t = torch.zeros_like(x).uniform_(0, 1.0 / 256)
+        arrays[f"step{step}/noise_s"], arrays[f"step{step}/noise_t"] = n_s, n_t
+        torch.manual_seed(70 + step)
+        opt.zero_grad()
+        s_z, s_nll, _ = student(x, None)               # mutates x in place
+        with torch.no_grad():
+            t_z, _, _ = teacher(x, None)               # sees student noise + its own
+        assert torch.allclose(x, arrays[f"step{step}/x"] + n_s + n_t, atol=0, rtol=0)
+        kd_val = None
+        for si, ti in zip(s_idx, t_idx):
+            d = torch.nn.functional.mse_loss(s_z[si], t_z[ti], reduction="none")
+            d = d.mean(dim=list(range(d.dim()))[1:])
+            kd_val = d if kd_val is None else kd_val + d
+        kd_val = kd_val / len(s_idx)
+        res = (0.9 * s_nll + 0.1 * kd_val).mean()
+        res.backward()
+        gn = torch.nn.utils.clip_grad_norm_(student.parameters(), 30.0)
+        for k, p in student.named_parameters():
+            arrays[f"step{step}/grad/{k}"] = p.grad.clone()
+        opt.step()
+        arrays[f"step{step}/nll"] = s_nll.mean()
+        arrays[f"step{step}/kd"] = kd_val.mean()
+        arrays[f"step{step}/loss"] = res
+        arrays[f"step{step}/grad_norm"] = gn
+        for k, v in student.state_dict().items():
+            arrays[f"step{step}/s_sd_after/{k}"] = v.clone()
+    save("distill8", {"student": s_cfg, "teacher": t_cfg}, arrays)
+
+
+def checksum_case(name, cfg, batch, seed):
+    """Full-size models: parameters are rebuilt from (shapes, seed) by the tests, only
+    per-layer checksums and bpd are stored."""
+    model, _ = build(cfg, seed)
+    h, w, c = cfg["image_shape"]
+    x, noise = synthetic_images(batch, (c, h, w), seed=seed + 5)
+    xin = x + noise
+    with torch.no_grad():
+        ld0 = torch.full((batch,), -math.log(256.0) * c * h * w)
+        outs, obj = model.flow(xin.clone(), y_onehot=None, logdet=ld0, reverse=False)
+        mean, logs = model.prior(xin, None)
+        obj = obj + layers.gaussian_likelihood(mean, logs, outs[-1])
+        bpd = -obj / (math.log(2.0) * c * h * w)
+    arrays = {"bpd": bpd, "objective": obj,
+              "out_mean": torch.stack([o.double().mean() for o in outs]),
+              "out_absmean": torch.stack([o.double().abs().mean() for o in outs]),
+              "seed": np.array(seed), "batch": np.array(batch)}
+    save(name, cfg, arrays)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    primitive_case()
+    model_case("glow8", base_cfg(), 2, 101)
+    model_case("glow32", base_cfg(image_shape=[32, 32, 3], hidden_channels=32, L=3), 2, 102)
+    model_case("glow8_additive", base_cfg(flow_coupling="additive"), 2, 103)
+    model_case("glow8_nolu", base_cfg(LU_decomposed=False), 2, 104)
+    model_case("glow8_shuffle", base_cfg(flow_permutation="shuffle"), 2, 105)
+    model_case("glow8_reverse", base_cfg(flow_permutation="reverse"), 2, 106)
+    model_case("glow8_learntop", base_cfg(learn_top=True), 2, 107)
+    model_case("glow16_h24", base_cfg(image_shape=[16, 16, 3], hidden_channels=24, K=3, L=2), 3, 108)
+    tab = dict(L=1, is_1d=True, y_classes=0)
+    model_case("tab6", base_cfg(image_shape=[6], K=2, **tab), 8, 111)
+    model_case("tab63", base_cfg(image_shape=[63], K=2, **tab), 8, 112)
+    model_case("tab6_k5_h32", base_cfg(image_shape=[6], K=5, hidden_channels=32, **tab), 16, 113)
+    model_case("tab5_cond", base_cfg(image_shape=[5], K=2, L=1, is_1d=True, y_classes=3,
+                                     y_condition=True, learn_top=True), 8, 114)
+    distill_case()
+    cifar = dict(image_shape=[32, 32, 3], hidden_channels=512, L=3)
+    checksum_case("cifar_k8_full", base_cfg(K=8, **cifar), 4, 201)
+    checksum_case("cifar_k32_full", base_cfg(K=32, **cifar), 2, 202)
+    checksum_case("celeba_l4_k32_full",
+                  base_cfg(image_shape=[64, 64, 3], hidden_channels=512, K=32, L=4), 1, 203)

@@ -1,0 +1,181 @@
+"""Pin the CPU oracle (oracle/glow_oracle.py) to vectors produced by the reference's own code.
+
+Runs on CPU (no GPU needed).  Tolerances: the reference and the oracle are both fp32 torch-CPU
+programs with different op orderings (e.g. einsum vs conv2d for the 1x1 conv), so outputs are
+compared to 2e-5 relative-to-max (layer outputs of deep stacks) and log-densities to 2e-6 relative.
+"""
+import math
+
+import pytest
+import torch
+
+from golden_util import Golden, rel_err
+from oracle import glow_oracle as O
+from param_util import randomize_state_dict, synthetic_images
+
+MODEL_CASES = ["glow8", "glow32", "glow8_additive", "glow8_nolu", "glow8_shuffle",
+               "glow8_reverse", "glow8_learntop", "glow16_h24", "tab6", "tab63", "tab6_k5_h32",
+               "tab5_cond"]
+
+
+def test_primitives():
+    g = Golden("primitives")
+    assert torch.equal(O.squeeze2(g.t("squeeze/x")), g.t("squeeze/y"))
+    assert torch.equal(O.unsqueeze2(g.t("squeeze/y")), g.t("unsqueeze/y"))
+    lp = O.gaussian_logp(g.t("gauss/mean"), g.t("gauss/logs"), g.t("gauss/x"))
+    assert rel_err(lp, g.t("gauss/lp")) < 1e-6
+    for tag in ("an2d", "an1d"):
+        y, ld = O.actnorm(g.t(f"{tag}/bias"), g.t(f"{tag}/logs"), g.t(f"{tag}/x"), g.t(f"{tag}/ld"), False)
+        assert rel_err(y, g.t(f"{tag}/y")) < 1e-6 and rel_err(ld, g.t(f"{tag}/ldo")) < 1e-6
+        y, ld = O.actnorm(g.t(f"{tag}/bias"), g.t(f"{tag}/logs"), g.t(f"{tag}/x"), g.t(f"{tag}/ld"), True)
+        assert rel_err(y, g.t(f"{tag}/yi")) < 1e-6 and rel_err(ld, g.t(f"{tag}/ldi")) < 1e-6
+    for tag in ("ic2d", "ic1d", "ic2d_nolu"):
+        sd = g.group(f"{tag}/sd")
+        y, ld = O.invconv(sd, "invconv.", g.t(f"{tag}/x"), g.t(f"{tag}/ld"), False)
+        assert rel_err(y, g.t(f"{tag}/y")) < 2e-6 and rel_err(ld, g.t(f"{tag}/ldo")) < 2e-6
+        y, ld = O.invconv(sd, "invconv.", g.t(f"{tag}/x"), g.t(f"{tag}/ld"), True)
+        assert rel_err(y, g.t(f"{tag}/yi")) < 2e-5 and rel_err(ld, g.t(f"{tag}/ldi")) < 2e-6
+    sd = g.group("split/sd")
+    z1, ld = O.split2d(sd, "", g.t("split/x"), g.t("split/ld"), False)
+    assert torch.equal(z1, g.t("split/z1")) and rel_err(ld, g.t("split/ldo")) < 2e-6
+    zr, _ = O.split2d(sd, "", g.t("split/z1"), 0.0, True, temperature=0.0)
+    assert rel_err(zr, g.t("split/rev")) < 2e-6
+
+
+def _perms(g):
+    return {int(k): v for k, v in g.group("perm").items()} or None
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_model_forward_backward_reverse(name):
+    g = Golden(name)
+    cfg = g.cfg
+    sd = g.group("sd")
+    trainable = [k for k in sd if not O.is_buffer(k)]
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    x = g.t("x").clone()
+    y = g.t("y") if g.has("y") else None
+    noise = g.t("noise") if g.has("noise") else None
+    outs, bpd, y_logits = O.glow_forward(sd, cfg, x, y, noise, _perms(g))
+    if noise is not None:
+        assert torch.equal(x, g.t("x") + noise)  # in-place mutation like models/utils.py:38
+    ref_outs = g.seq("out")
+    assert len(outs) == len(ref_outs) == len(O.layer_schedule(cfg))
+    for o, r in zip(outs, ref_outs):
+        assert o.shape == r.shape
+        assert rel_err(o, r) < 2e-5
+    assert rel_err(bpd, g.t("bpd")) < 2e-6
+    loss = bpd.mean()
+    if y_logits is not None:
+        assert rel_err(y_logits, g.t("y_logits")) < 2e-5
+        loss = loss + 0.1 * (y_logits ** 2).sum()
+    loss.backward()
+    for k in trainable:
+        ref = g.t(f"grad/{k}")
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(ref)
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert float(got.abs().max()) < 1e-7, k
+        else:
+            assert rel_err(got, ref) < 5e-4, k
+    with torch.no_grad():
+        rev = O.glow_reverse(sd, cfg, outs[-1].detach(), y, temperature=0.0, perms=_perms(g))
+        for o, r in zip(rev, g.seq("rev")):
+            assert rel_err(o, r) < 5e-5
+        mean, logs = O.prior(sd, cfg, x.shape[0], y)
+        assert rel_err(mean, g.t("prior_mean")) < 1e-6 or float(g.t("prior_mean").abs().max()) == 0
+        assert rel_err(logs, g.t("prior_logs")) < 1e-6 or float(g.t("prior_logs").abs().max()) == 0
+
+
+def test_fp64_oracle_matches_fp64_reference():
+    """The oracle in fp64 against the reference run in fp64: pins the algorithm much tighter
+    than fp32 rounding allows."""
+    g = Golden("glow32")
+    sd = g.group("sd", torch.float64)
+    x = (g.t("x") + g.t("noise")).double()
+    outs, ld = O.encode(sd, g.cfg, x, O.dequant_logdet(x))
+    assert rel_err(ld, g.t("logdet64")) < 1e-12
+    assert rel_err(outs[-1], g.t("last64")) < 1e-11
+
+
+def test_kd_indices_match_survey():
+    cif = dict(image_shape=[32, 32, 3], L=3, is_1d=False)
+    s, t = O.kd_indices(dict(K=8, **cif), dict(K=32, **cif))
+    assert s == [0, 10, 20, 28] and t == [0, 34, 68, 100]
+    tab = dict(image_shape=[6], L=1, is_1d=True)
+    s, t = O.kd_indices(dict(K=3, **tab), dict(K=5, **tab))
+    assert s == [1, 2] and t == [3, 4]
+
+
+def test_distillation_step():
+    g = Golden("distill8")
+    s_cfg, t_cfg = g.cfg["student"], g.cfg["teacher"]
+    s_sd, t_sd = g.group("s_sd"), g.group("t_sd")
+    s_idx, t_idx = O.kd_indices(s_cfg, t_cfg)
+    assert s_idx == g.t("s_idx").tolist() and t_idx == g.t("t_idx").tolist()
+    state = {}
+    for step in range(2):
+        p = f"step{step}/"
+        x = g.t(p + "x").clone()
+        res = O.distill_step(s_sd, s_cfg, t_sd, t_cfg, x, g.t(p + "noise_s"), g.t(p + "noise_t"), state)
+        assert rel_err(res["nll"], g.t(p + "nll")) < 2e-6
+        assert rel_err(res["kd"], g.t(p + "kd")) < 1e-4
+        assert rel_err(res["result_loss"], g.t(p + "loss")) < 2e-6
+        assert rel_err(res["grad_norm"], g.t(p + "grad_norm")) < 1e-4
+        for k, ref in g.group(p + "s_sd_after").items():
+            # Adam's first steps move every weight by ~lr regardless of gradient scale
+            assert float((s_sd[k] - ref).abs().max()) < 2e-5, k
+
+
+@pytest.mark.parametrize("name", ["cifar_k8_full", "cifar_k32_full"])
+def test_full_size_checksums(name):
+    g = Golden(name)
+    cfg = g.cfg
+    shapes = full_shapes(cfg)
+    sd = randomize_state_dict(shapes, int(g.t("seed")))
+    h, w, c = cfg["image_shape"]
+    b = int(g.t("batch"))
+    x, noise = synthetic_images(b, (c, h, w), seed=int(g.t("seed")) + 5)
+    with torch.no_grad():
+        outs, bpd, _ = O.glow_forward(sd, cfg, x, None, noise)
+    assert rel_err(bpd, g.t("bpd")) < 2e-6
+    got = torch.stack([o.double().abs().mean() for o in outs])
+    assert rel_err(got, g.t("out_absmean")) < 1e-5
+
+
+def full_shapes(cfg):
+    """state_dict key -> shape in the reference's order (buffers first: prior_h), for LU/affine
+    2-D configs; matches what the reference's state_dict() yields."""
+    hid = cfg["hidden_channels"]
+    shapes = {}
+    sched = O.layer_schedule(cfg)
+    c_top, h_top, w_top = sched[-1][1]
+    shapes["prior_h"] = (1, 2 * c_top, h_top, w_top)
+    c_in = None
+    for i, (kind, shp) in enumerate(sched):
+        p = f"flow.layers.{i}."
+        if kind == "step":
+            c = shp[0]
+            shapes[p + "actnorm.bias"] = (1, c, 1, 1)
+            shapes[p + "actnorm.logs"] = (1, c, 1, 1)
+            shapes[p + "invconv.lower"] = (c, c)
+            shapes[p + "invconv.log_s"] = (c,)
+            shapes[p + "invconv.upper"] = (c, c)
+            shapes[p + "invconv.p"] = (c, c)
+            shapes[p + "invconv.sign_s"] = (c,)
+            shapes[p + "block.0.conv.weight"] = (hid, c // 2, 3, 3)
+            shapes[p + "block.0.actnorm.bias"] = (1, hid, 1, 1)
+            shapes[p + "block.0.actnorm.logs"] = (1, hid, 1, 1)
+            shapes[p + "block.2.conv.weight"] = (hid, hid, 1, 1)
+            shapes[p + "block.2.actnorm.bias"] = (1, hid, 1, 1)
+            shapes[p + "block.2.actnorm.logs"] = (1, hid, 1, 1)
+            shapes[p + "block.4.logs"] = (c, 1, 1)
+            shapes[p + "block.4.conv.weight"] = (c, hid, 3, 3)
+            shapes[p + "block.4.conv.bias"] = (c,)
+        elif kind == "split":
+            c = shp[0] * 2
+            shapes[p + "conv.logs"] = (c, 1, 1)
+            shapes[p + "conv.conv.weight"] = (c, c // 2, 3, 3)
+            shapes[p + "conv.conv.bias"] = (c,)
+    return shapes
