@@ -1,0 +1,177 @@
+/* nfk -- MI355X (gfx950) native kernels for the Glow coupling-flow hot path.
+ *
+ * C ABI of libnfk.so.  Plain pointers and sizes only: every pointer is a DEVICE pointer to
+ * fp32 data unless stated otherwise, `stream` is a hipStream_t passed as void*, every function
+ * returns 0 on success (NFK_ERR_* otherwise), nothing is allocated or synchronised inside, all
+ * work is enqueued on the caller's stream (so a caller may capture it into a hipGraph).
+ *
+ * The reference (vklyukin/nf_distillation) has no FFI: its hot path is eager PyTorch.  Each entry
+ * point below names the reference code it replaces (file:line under /root/reference).
+ *
+ * Activation layout: NHWC, i.e. rows of C channels per pixel, M = B*H*W rows ("ld*" = row stride
+ * in floats).  1-D (tabular) data is the H = W = 1 case.
+ */
+#ifndef NFK_H_
+#define NFK_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFK_OK 0
+#define NFK_ERR_ARG 1
+#define NFK_ERR_LAUNCH 2
+
+enum { NFK_PERM_LU = 0, NFK_PERM_DENSE = 1, NFK_PERM_INDEX = 2 };
+
+/* Parameter products of one FlowStep (ActNorm + permutation) and the exp() of the coupling
+ * net's log-scales.  An array of these lives in DEVICE memory; one launch serves all steps.
+ * Replaces models/layers.py:107-127 (_ActNorm._scale), :360-402 (InvertibleConv1x1.get_weight),
+ * :227 / :260 (exp(logs) of ActNorm2d inside Conv2d, exp(3 logs) of Conv2dZeros). */
+typedef struct nfk_prep_desc {
+  int32_t C;          /* channels mixed by this step; 0 = no mixing (Split2d / learn_top conv) */
+  int32_t pixels;     /* H*W (1 for 1-D): multiplies the parameter log-det                       */
+  int32_t is_1d;      /* 1: z = y @ W (models/layers.py:411), 0: z = W y per pixel (:413)        */
+  int32_t perm_kind;  /* NFK_PERM_*                                                              */
+  int32_t n1, n2, n3; /* lengths of l1,l2 (ActNorm logs of block.0/.2) and l3 (Conv2dZeros logs) */
+  int32_t pad_;
+  const float *an_bias, *an_logs;                   /* [C]                    */
+  const float *lower, *upper, *log_s, *p, *sign_s;  /* LU parametrisation     */
+  const float *weight;                              /* dense [C][C]           */
+  const int32_t *perm_idx;                          /* [C] forward gather idx */
+  const float *l1, *l2, *l3;
+  /* outputs */
+  float *Wf, *cf;     /* fused forward matrix [C][C] (out-major) and offset [C]        */
+  float *Wi, *ci;     /* fused inverse matrix / offset (written when want_inverse)     */
+  float *dld;         /* [1] pixels * (sum logs + sum log|s|)                          */
+  float *es1, *es2, *es3;
+  float *scratch;     /* >= 5*C*C floats */
+} nfk_prep_desc;
+
+/* Where the backward of `prep` reads its partial sums and accumulates parameter gradients. */
+typedef struct nfk_prep_grad {
+  const float *part;  /* [nparts][C*C + C] partial (gWf, gcf) written by nfk_chanmix_bwd */
+  int32_t nparts, pad_;
+  float *g_an_bias, *g_an_logs, *g_lower, *g_upper, *g_log_s, *g_weight;
+} nfk_prep_grad;
+
+/* One 2-D FlowStep (models/flows.py:55-202) with a 3-conv coupling net (models/flows.py:25-34). */
+typedef struct nfk_step2d {
+  int32_t B, H, W, C, hidden, Cout; /* Cout = C - C/2 (additive) or 2*(C - C/2) (affine) */
+  int32_t additive, pad_;
+  const float *b1, *b2, *bias3;     /* block.0/.2 actnorm.bias [hidden], block.4 conv.bias [Cout] */
+  const float *Wf, *cf, *Wi, *ci, *dld, *es1, *es2, *es3; /* from nfk_prep */
+  const float *wt1, *wt2, *wt3;     /* repacked forward weights [N][Kp]  (nfk_repack) */
+  const float *wd1, *wd2, *wd3;     /* repacked dgrad weights            (nfk_repack) */
+} nfk_step2d;
+
+typedef struct nfk_step2d_grads {   /* all accumulate (+=) */
+  float *g_w1, *g_b1, *g_l1, *g_w2, *g_b2, *g_l2, *g_w3, *g_bias3, *g_l3;
+  float *mix_part;                  /* [nfk_chanmix_blocks(M)][C*C + C], consumed by nfk_prep_bwd */
+} nfk_step2d_grads;
+
+/* Split2d (models/layers.py:293-313): Conv2dZeros(C/2 -> C) prior on the dropped half. */
+typedef struct nfk_split2d {
+  int32_t B, H, W, C;
+  const float *bias, *es;           /* conv.bias [C], exp(3 logs) [C] (prep es3) */
+  const float *wt, *wd;             /* repacked weights */
+} nfk_split2d;
+
+/* One conv weight to repack (see nfk_repack); DEVICE array for nfk_repack_batch. */
+typedef struct nfk_repack_desc {
+  const float *w;
+  float *wt, *wd; /* wd may be NULL */
+  int32_t Cout, Cin, taps, pad_;
+} nfk_repack_desc;
+
+typedef struct nfk_small_grad_args {
+  const float *col1, *col2, *tail;
+  int32_t mb1, mb2, B, n1, n2, n3;
+  float *g_l1, *g_b1, *g_l2, *g_b2, *g_bias3, *g_l3;
+} nfk_small_grad_args;
+
+/* ---- sizes ------------------------------------------------------------------------------- */
+int nfk_padded_k(int K);                          /* K rounded up to the k-chunk (32)            */
+int nfk_conv_splitk(int M, int N, int K);         /* slabs written by a raw-output conv          */
+int nfk_chanmix_blocks(int M);
+size_t nfk_step2d_fwd_ws_floats(const nfk_step2d *s);   /* a3 slab workspace                   */
+size_t nfk_step2d_bwd_ws_floats(const nfk_step2d *s);
+size_t nfk_split2d_fwd_ws_floats(const nfk_split2d *s);
+size_t nfk_split2d_bwd_ws_floats(const nfk_split2d *s);
+
+/* ---- parameter-side kernels ---------------------------------------------------------------- */
+/* descs: DEVICE array[nsteps].  One workgroup per step. */
+int nfk_prep(const nfk_prep_desc *descs, int nsteps, int want_inverse, void *stream);
+int nfk_prep_bwd(const nfk_prep_desc *descs, const nfk_prep_grad *grads, int nsteps, const float *g_logdet,
+                 int B, int any_dense, void *stream);
+/* conv.weight [Cout][Cin][taps] -> wt [Cout][Kp(taps*Cin)] and (optional) wd [Cin][Kp(taps*Cout)]
+ * (flipped taps).  Replaces nn.ZeroPad2d + nn.Conv2d weight handling (models/layers.py:208-211). */
+int nfk_repack(const float *w, int Cout, int Cin, int taps, float *wt, float *wd, void *stream);
+/* all conv weights of a model in one launch; descs: DEVICE array[n] */
+int nfk_repack_batch(const nfk_repack_desc *descs, int n, void *stream);
+
+/* ---- op-level entry points (unit-testable primitives) -------------------------------------- */
+/* z[m][:] = Wm x[m][:] + cv   -- _ActNorm.forward + InvertibleConv1x1.forward / Permute2d
+ * (models/layers.py:129-142, 404-421, 283-290) in either direction, given prep's (Wf,cf)/(Wi,ci). */
+int nfk_chanmix(const float *x, int ldx, const float *Wm, const float *cv, float *z, int ldz, int M, int C,
+                void *stream);
+/* implicit-GEMM convolution on the matrix cores; epi: 0 raw slabs, 1 (acc+e0)*e1 then ReLU.
+ * Replaces Conv2d.forward / Conv2dZeros.forward (models/layers.py:223-228, 257-260). */
+int nfk_conv(const float *x, int ldx, int B, int H, int W, int Cin, int taps, const float *wt, int N, float *out,
+             int ldo, int epi, const float *e0, const float *e1, void *stream);
+/* affine / additive coupling tail + per-sample log-det (models/flows.py:157-169 / 182-194) */
+int nfk_coupling_fwd(const float *a3, int S, const float *bias3, const float *es3, const float *z, int ldz,
+                     float *zout, int ldo, float *hsave, const float *ld_in, const float *dld, float *ld_out,
+                     int B, int HW, int C, int Cout, int additive, void *stream);
+int nfk_coupling_inv(const float *a3, int S, const float *bias3, const float *es3, const float *y, int ldy,
+                     float *z, int ldz, const float *ld_in, const float *dld, float *ld_out, int B, int HW,
+                     int C, int Cout, int additive, void *stream);
+/* squeeze2d / unsqueeze2d (models/layers.py:32-61).  from_nchw: x is the NCHW model input, optionally
+ * with the in-place dequantisation noise of uniform_binning_correction (models/utils.py:38). */
+int nfk_squeeze(float *x, int ldx, const float *noise, float *out, int B, int C, int H, int W, int from_nchw,
+                void *stream);
+int nfk_unsqueeze(const float *y, float *out, int B, int C, int H, int W, int to_nchw, void *stream);
+/* Glow.normal_flow tail (models/kd_flows.py:136-150): objective = logdet + log N(z; prior), bits/dim */
+int nfk_prior_fwd(const float *z, int ldz, const float *prior, long prior_bstride, const float *ld,
+                  float *objective, float *bpd, int B, int HW, int C, float bpd_scale, void *stream);
+int nfk_prior_bwd(const float *z, int ldz, const float *prior, long prior_bstride, const float *g_bpd,
+                  float *g_z, int ldgz, float *g_ld, float *g_prior, int B, int HW, int C, float bpd_scale,
+                  void *stream);
+
+/* ---- layer-level composites ---------------------------------------------------------------- */
+/* FlowStep.normal_flow (models/flows.py:142-171).  z,h1,h2,hsave are the activations kept for the
+ * backward (hsave may be NULL when no backward follows; z/h1/h2 may then be reused scratch). */
+int nfk_step2d_fwd(const nfk_step2d *s, const float *x, int ldx, const float *ld_in, float *z, float *h1,
+                   float *h2, float *hsave, float *ws, float *zout, float *ld_out, void *stream);
+/* FlowStep.reverse_flow (models/flows.py:173-202): y -> x.  ld_* may be NULL. */
+int nfk_step2d_inv(const nfk_step2d *s, const float *y, int ldy, const float *ld_in, float *z, float *h1,
+                   float *h2, float *ws, float *xout, float *ld_out, void *stream);
+/* backward of nfk_step2d_fwd: g_out (+ optional g_ext) and g_ld -> g_x, parameter grads. */
+int nfk_step2d_bwd(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
+                   const float *h1, const float *h2, const float *hsave, const float *g_out,
+                   const float *g_ext, const float *g_ld, float *g_x, float *ws, void *stream);
+/* Split2d.forward / reverse / backward */
+int nfk_split2d_fwd(const nfk_split2d *s, const float *x, const float *ld_in, float *z1out, float *hsave,
+                    float *ws, float *ld_out, void *stream);
+int nfk_split2d_inv(const nfk_split2d *s, const float *z1, const float *eps, float temperature, float *xout,
+                    float *ws, void *stream);
+int nfk_split2d_bwd(const nfk_split2d *s, const float *x, const float *hsave, const float *g_z1,
+                    const float *g_ext, const float *g_ld, float *g_x, float *g_w, float *g_bias,
+                    float *g_logs, float *ws, void *stream);
+
+/* ---- optimiser (torch.optim.Adam + clip_grad_norm_, pl_module.py:350-354, train.py:46) ------ */
+/* sumsq[0] += sum g^2 over n elements (deterministic two-stage tree); partial: >= 1024 floats */
+int nfk_sumsq(const float *g, size_t n, float *partial, float *sumsq, void *stream);
+/* p -= lr_t * m_hat / (sqrt(v_hat) + eps) with g scaled by min(1, clip/(sqrt(sumsq)+1e-6)) * gscale */
+int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const float *sumsq, float clip,
+                  float gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  void *stream);
+
+const char *nfk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFK_H_ */

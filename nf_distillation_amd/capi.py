@@ -1,0 +1,149 @@
+"""ctypes binding of libnfk.so (the C ABI declared in include/nfk.h).
+
+There is no CPU fallback: importing the package works without the library (so that host-side
+logic can be unit-tested), but the first use of any kernel raises ``NfkUnavailable`` if
+``libnfk.so`` has not been built (``python -c 'import __graft_entry__ as g; g.build()'``).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnfk.so")
+
+c_fp = C.c_void_p  # device float*
+
+
+class NfkUnavailable(RuntimeError):
+    pass
+
+
+class NfkError(RuntimeError):
+    pass
+
+
+class PrepDesc(C.Structure):
+    _fields_ = [("C", C.c_int32), ("pixels", C.c_int32), ("is_1d", C.c_int32), ("perm_kind", C.c_int32),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("n3", C.c_int32), ("pad_", C.c_int32),
+                ("an_bias", c_fp), ("an_logs", c_fp),
+                ("lower", c_fp), ("upper", c_fp), ("log_s", c_fp), ("p", c_fp), ("sign_s", c_fp),
+                ("weight", c_fp), ("perm_idx", c_fp),
+                ("l1", c_fp), ("l2", c_fp), ("l3", c_fp),
+                ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp),
+                ("es1", c_fp), ("es2", c_fp), ("es3", c_fp), ("scratch", c_fp)]
+
+
+class PrepGrad(C.Structure):
+    _fields_ = [("part", c_fp), ("nparts", C.c_int32), ("pad_", C.c_int32),
+                ("g_an_bias", c_fp), ("g_an_logs", c_fp), ("g_lower", c_fp), ("g_upper", c_fp),
+                ("g_log_s", c_fp), ("g_weight", c_fp)]
+
+
+class Step2d(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("hidden", C.c_int32), ("Cout", C.c_int32), ("additive", C.c_int32), ("pad_", C.c_int32),
+                ("b1", c_fp), ("b2", c_fp), ("bias3", c_fp),
+                ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp),
+                ("es1", c_fp), ("es2", c_fp), ("es3", c_fp),
+                ("wt1", c_fp), ("wt2", c_fp), ("wt3", c_fp), ("wd1", c_fp), ("wd2", c_fp), ("wd3", c_fp)]
+
+
+class Step2dGrads(C.Structure):
+    _fields_ = [("g_w1", c_fp), ("g_b1", c_fp), ("g_l1", c_fp), ("g_w2", c_fp), ("g_b2", c_fp),
+                ("g_l2", c_fp), ("g_w3", c_fp), ("g_bias3", c_fp), ("g_l3", c_fp), ("mix_part", c_fp)]
+
+
+class Split2d(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("bias", c_fp), ("es", c_fp), ("wt", c_fp), ("wd", c_fp)]
+
+
+class RepackDesc(C.Structure):
+    _fields_ = [("w", c_fp), ("wt", c_fp), ("wd", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("taps", C.c_int32), ("pad_", C.c_int32)]
+
+
+i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long
+
+_PROTOS = {
+    "nfk_version": (C.c_char_p, []),
+    "nfk_padded_k": (i32, [i32]),
+    "nfk_conv_splitk": (i32, [i32, i32, i32]),
+    "nfk_chanmix_blocks": (i32, [i32]),
+    "nfk_step2d_fwd_ws_floats": (u64, [C.POINTER(Step2d)]),
+    "nfk_step2d_bwd_ws_floats": (u64, [C.POINTER(Step2d)]),
+    "nfk_split2d_fwd_ws_floats": (u64, [C.POINTER(Split2d)]),
+    "nfk_split2d_bwd_ws_floats": (u64, [C.POINTER(Split2d)]),
+    "nfk_prep": (i32, [vp, i32, i32, vp]),
+    "nfk_prep_bwd": (i32, [vp, vp, i32, vp, i32, i32, vp]),
+    "nfk_repack": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "nfk_repack_batch": (i32, [vp, i32, vp]),
+    "nfk_chanmix": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "nfk_conv": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
+    "nfk_coupling_fwd": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nfk_coupling_inv": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nfk_squeeze": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nfk_unsqueeze": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nfk_prior_fwd": (i32, [vp, i32, vp, lng, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "nfk_prior_bwd": (i32, [vp, i32, vp, lng, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
+    "nfk_step2d_fwd": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_step2d_inv": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_step2d_bwd": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp,
+                             vp, vp]),
+    "nfk_split2d_fwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_split2d_inv": (i32, [C.POINTER(Split2d), vp, vp, f32, vp, vp, vp]),
+    "nfk_split2d_bwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_sumsq": (i32, [vp, u64, vp, vp, vp]),
+    "nfk_adam_step": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises NfkUnavailable if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NfkUnavailable(
+                f"{LIB_PATH} not found: build the HIP library first "
+                "(`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def check(rc, what="nfk call"):
+    if rc != 0:
+        raise NfkError(f"{what} failed with status {rc}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_cuda(t, what="input"):
+    if not t.is_cuda:
+        raise NfkUnavailable(f"{what} is on {t.device}: the nfk kernels run on MI355X only (no CPU fallback)")
+
+
+def struct_array_to_device(items, device):
+    """Upload a list of ctypes structs as a contiguous device byte tensor."""
+    if not items:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    arr = (type(items[0]) * len(items))(*items)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)

@@ -1,0 +1,314 @@
+// libnfk C ABI (include/nfk.h): layer-level composites that chain the nfk kernels on the
+// caller's stream, plus thin op-level wrappers used by the unit parity tests.
+#include "nfk_internal.h"
+
+using namespace nfk;
+
+namespace {
+inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align4(size_t n) { return (n + 3) & ~size_t(3); }
+#define NFK_TRY(expr)            \
+  do {                           \
+    const int rc_ = (expr);      \
+    if (rc_ != NFK_OK) return rc_; \
+  } while (0)
+
+struct StepBwdWs {
+  size_t ga3, gz, ga2, ga1, d1slab, col2, col1, tail, wslab, total;
+  int S1, S3w, S2w, S1w, mb;
+};
+StepBwdWs step_bwd_layout(const nfk_step2d* s) {
+  StepBwdWs w;
+  const size_t M = (size_t)s->B * s->H * s->W;
+  const int Ch = s->C / 2, hid = s->hidden;
+  w.S1 = conv_splitk((int)M, Ch, 9 * hid, EPI_RAW);
+  w.S3w = wgrad_splits((int)M, s->Cout, 9 * hid);
+  w.S2w = wgrad_splits((int)M, hid, hid);
+  w.S1w = wgrad_splits((int)M, hid, 9 * Ch);
+  w.mb = conv_mblocks((int)M, hid);
+  size_t o = 0;
+  w.ga3 = o; o += align4(M * s->Cout);
+  w.gz = o; o += align4(M * s->C);
+  w.ga2 = o; o += align4(M * hid);
+  w.ga1 = o; o += align4(M * hid);
+  w.d1slab = o; o += align4((size_t)w.S1 * M * Ch);
+  w.col2 = o; o += align4((size_t)w.mb * 2 * hid);
+  w.col1 = o; o += align4((size_t)w.mb * 2 * hid);
+  w.tail = o; o += align4((size_t)s->B * 2 * s->Cout);
+  size_t ws = (size_t)w.S3w * s->Cout * 9 * hid;
+  const size_t ws2 = (size_t)w.S2w * hid * hid, ws1 = (size_t)w.S1w * hid * 9 * Ch;
+  if (ws2 > ws) ws = ws2;
+  if (ws1 > ws) ws = ws1;
+  w.wslab = o; o += align4(ws);
+  w.total = o;
+  return w;
+}
+
+ConvGemmArgs conv_args(const float* X, int ldx, int B, int H, int W, int Cin, int taps, const float* Wt, int N,
+                       float* out, int ldo, int epi) {
+  ConvGemmArgs a{};
+  a.X = X; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.taps = taps;
+  a.Wt = Wt; a.Kp = padded_k(taps * Cin); a.N = N;
+  a.out = out; a.ldo = ldo; a.slab_stride = (long)B * H * W * ldo; a.epi = epi;
+  return a;
+}
+}  // namespace
+
+extern "C" {
+
+const char* nfk_version(void) { return "nfk 0.1 (gfx950, f32 MFMA)"; }
+
+int nfk_padded_k(int K) { return padded_k(K); }
+int nfk_conv_splitk(int M, int N, int K) { return conv_splitk(M, N, K, EPI_RAW); }
+int nfk_chanmix_blocks(int M) { return chanmix_blocks(M); }
+
+size_t nfk_step2d_fwd_ws_floats(const nfk_step2d* s) {
+  const size_t M = (size_t)s->B * s->H * s->W;
+  return align4((size_t)conv_splitk((int)M, s->Cout, 9 * s->hidden, EPI_RAW) * M * s->Cout);
+}
+size_t nfk_step2d_bwd_ws_floats(const nfk_step2d* s) { return step_bwd_layout(s).total; }
+size_t nfk_split2d_fwd_ws_floats(const nfk_split2d* s) {
+  const size_t M = (size_t)s->B * s->H * s->W;
+  return align4((size_t)conv_splitk((int)M, s->C, 9 * (s->C / 2), EPI_RAW) * M * s->C);
+}
+size_t nfk_split2d_bwd_ws_floats(const nfk_split2d* s) {
+  const size_t M = (size_t)s->B * s->H * s->W;
+  const int Ch = s->C / 2;
+  return align4(M * s->C) + align4((size_t)conv_splitk((int)M, Ch, 9 * s->C, EPI_RAW) * M * Ch) +
+         align4((size_t)s->B * 2 * s->C) + align4((size_t)wgrad_splits((int)M, s->C, 9 * Ch) * s->C * 9 * Ch);
+}
+
+int nfk_prep(const nfk_prep_desc* descs, int nsteps, int want_inverse, void* stream) {
+  return launch_prep(descs, nsteps, want_inverse, S_(stream));
+}
+int nfk_prep_bwd(const nfk_prep_desc* descs, const nfk_prep_grad* grads, int nsteps, const float* g_logdet, int B,
+                 int any_dense, void* stream) {
+  return launch_prep_bwd(descs, grads, nsteps, g_logdet, B, any_dense, S_(stream));
+}
+int nfk_repack(const float* w, int Cout, int Cin, int taps, float* wt, float* wd, void* stream) {
+  if (taps != 1 && taps != 9) return NFK_ERR_ARG;
+  return repack_weights(w, Cout, Cin, taps, wt, wd, S_(stream));
+}
+
+int nfk_repack_batch(const nfk_repack_desc* descs, int n, void* stream) { return repack_batch(descs, n, S_(stream)); }
+
+int nfk_chanmix(const float* x, int ldx, const float* Wm, const float* cv, float* z, int ldz, int M, int C,
+                void* stream) {
+  ChanMixArgs a{};
+  a.x = x; a.ldx = ldx; a.Wm = Wm; a.cv = cv; a.z = z; a.ldz = ldz; a.M = M; a.C = C;
+  return launch_chanmix(a, S_(stream));
+}
+
+int nfk_conv(const float* x, int ldx, int B, int H, int W, int Cin, int taps, const float* wt, int N, float* out,
+             int ldo, int epi, const float* e0, const float* e1, void* stream) {
+  if (epi != EPI_RAW && epi != EPI_AN_RELU) return NFK_ERR_ARG;
+  ConvGemmArgs a = conv_args(x, ldx, B, H, W, Cin, taps, wt, N, out, ldo, epi);
+  a.e0 = e0; a.e1 = e1;
+  return conv_gemm(a, S_(stream));
+}
+
+int nfk_coupling_fwd(const float* a3, int S, const float* bias3, const float* es3, const float* z, int ldz,
+                     float* zout, int ldo, float* hsave, const float* ld_in, const float* dld, float* ld_out,
+                     int B, int HW, int C, int Cout, int additive, void* stream) {
+  CouplingArgs a{};
+  a.a3 = a3; a.S = S; a.slab_stride = (long)B * HW * Cout; a.bias3 = bias3; a.es3 = es3;
+  a.z = z; a.ldz = ldz; a.zout = zout; a.ldo = ldo; a.hsave = hsave;
+  a.ld_in = ld_in; a.dld = dld; a.ld_out = ld_out; a.has_ld = ld_out != nullptr;
+  a.HW = HW; a.C = C; a.Cout = Cout; a.additive = additive;
+  return launch_coupling_fwd(a, B, S_(stream));
+}
+int nfk_coupling_inv(const float* a3, int S, const float* bias3, const float* es3, const float* y, int ldy,
+                     float* z, int ldz, const float* ld_in, const float* dld, float* ld_out, int B, int HW, int C,
+                     int Cout, int additive, void* stream) {
+  CouplingArgs a{};
+  a.a3 = a3; a.S = S; a.slab_stride = (long)B * HW * Cout; a.bias3 = bias3; a.es3 = es3;
+  a.z = y; a.ldz = ldy; a.zout = z; a.ldo = ldz;
+  a.ld_in = ld_in; a.dld = dld; a.ld_out = ld_out; a.has_ld = ld_out != nullptr;
+  a.HW = HW; a.C = C; a.Cout = Cout; a.additive = additive;
+  return launch_coupling_inv(a, B, S_(stream));
+}
+
+int nfk_squeeze(float* x, int ldx, const float* noise, float* out, int B, int C, int H, int W, int from_nchw,
+                void* stream) {
+  if (from_nchw) return launch_squeeze_nchw(x, noise, out, B, C, H, W, S_(stream));
+  if (noise) return NFK_ERR_ARG;
+  return launch_squeeze_nhwc(x, ldx, out, B, C, H, W, S_(stream));
+}
+int nfk_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, void* stream) {
+  return launch_unsqueeze(y, out, B, C, H, W, to_nchw, S_(stream));
+}
+
+int nfk_prior_fwd(const float* z, int ldz, const float* prior, long prior_bstride, const float* ld,
+                  float* objective, float* bpd, int B, int HW, int C, float bpd_scale, void* stream) {
+  PriorArgs a{};
+  a.z = z; a.ldz = ldz; a.ph = prior; a.ph_bstride = prior_bstride; a.ld = ld; a.objective = objective;
+  a.bpd = bpd; a.HW = HW; a.C = C; a.bpd_scale = bpd_scale;
+  return launch_prior_fwd(a, B, S_(stream));
+}
+int nfk_prior_bwd(const float* z, int ldz, const float* prior, long prior_bstride, const float* g_bpd, float* g_z,
+                  int ldgz, float* g_ld, float* g_prior, int B, int HW, int C, float bpd_scale, void* stream) {
+  PriorBwdArgs a{};
+  a.z = z; a.ldz = ldz; a.ph = prior; a.ph_bstride = prior_bstride; a.gbpd = g_bpd; a.gz = g_z; a.ldgz = ldgz;
+  a.gld = g_ld; a.gph = g_prior; a.HW = HW; a.C = C; a.bpd_scale = bpd_scale;
+  return launch_prior_bwd(a, B, S_(stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// FlowStep composites
+// ------------------------------------------------------------------------------------------
+static int coupling_net_fwd(const nfk_step2d* s, const float* zin, int ldz, float* h1, float* h2, float* ws,
+                            hipStream_t st) {
+  const int Ch = s->C / 2, hid = s->hidden;
+  ConvGemmArgs c1 = conv_args(zin, ldz, s->B, s->H, s->W, Ch, 9, s->wt1, hid, h1, hid, EPI_AN_RELU);
+  c1.e0 = s->b1; c1.e1 = s->es1;
+  NFK_TRY(conv_gemm(c1, st));
+  ConvGemmArgs c2 = conv_args(h1, hid, s->B, s->H, s->W, hid, 1, s->wt2, hid, h2, hid, EPI_AN_RELU);
+  c2.e0 = s->b2; c2.e1 = s->es2;
+  NFK_TRY(conv_gemm(c2, st));
+  ConvGemmArgs c3 = conv_args(h2, hid, s->B, s->H, s->W, hid, 9, s->wt3, s->Cout, ws, s->Cout, EPI_RAW);
+  return conv_gemm(c3, st);
+}
+
+int nfk_step2d_fwd(const nfk_step2d* s, const float* x, int ldx, const float* ld_in, float* z, float* h1,
+                   float* h2, float* hsave, float* ws, float* zout, float* ld_out, void* stream) {
+  hipStream_t st = S_(stream);
+  const int M = s->B * s->H * s->W, HW = s->H * s->W;
+  if (s->C < 2 || s->hidden < 1) return NFK_ERR_ARG;
+  ChanMixArgs m{};
+  m.x = x; m.ldx = ldx; m.Wm = s->Wf; m.cv = s->cf; m.z = z; m.ldz = s->C; m.M = M; m.C = s->C;
+  NFK_TRY(launch_chanmix(m, st));
+  NFK_TRY(coupling_net_fwd(s, z, s->C, h1, h2, ws, st));
+  const int S = conv_splitk(M, s->Cout, 9 * s->hidden, EPI_RAW);
+  return nfk_coupling_fwd(ws, S, s->bias3, s->es3, z, s->C, zout, s->C, hsave, ld_in, s->dld, ld_out, s->B, HW,
+                          s->C, s->Cout, s->additive, stream);
+}
+
+int nfk_step2d_inv(const nfk_step2d* s, const float* y, int ldy, const float* ld_in, float* z, float* h1,
+                   float* h2, float* ws, float* xout, float* ld_out, void* stream) {
+  hipStream_t st = S_(stream);
+  const int M = s->B * s->H * s->W, HW = s->H * s->W;
+  if (!s->Wi || !s->ci) return NFK_ERR_ARG;
+  NFK_TRY(coupling_net_fwd(s, y, ldy, h1, h2, ws, st));
+  const int S = conv_splitk(M, s->Cout, 9 * s->hidden, EPI_RAW);
+  NFK_TRY(nfk_coupling_inv(ws, S, s->bias3, s->es3, y, ldy, z, s->C, ld_in, s->dld, ld_out, s->B, HW, s->C,
+                           s->Cout, s->additive, stream));
+  ChanMixArgs m{};
+  m.x = z; m.ldx = s->C; m.Wm = s->Wi; m.cv = s->ci; m.z = xout; m.ldz = s->C; m.M = M; m.C = s->C;
+  return launch_chanmix(m, st);
+}
+
+int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
+                   const float* h1, const float* h2, const float* hsave, const float* g_out, const float* g_ext,
+                   const float* g_ld, float* g_x, float* ws, void* stream) {
+  hipStream_t st = S_(stream);
+  const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, hid = s->hidden, Cout = s->Cout;
+  const int M = B * H * W, HW = H * W;
+  const StepBwdWs L = step_bwd_layout(s);
+  float *ga3 = ws + L.ga3, *gz = ws + L.gz, *ga2 = ws + L.ga2, *ga1 = ws + L.ga1, *d1 = ws + L.d1slab;
+  float *col2 = ws + L.col2, *col1 = ws + L.col1, *tail = ws + L.tail, *wslab = ws + L.wslab;
+
+  CouplingBwdArgs cb{};
+  cb.gout = g_out; cb.ldg = C; cb.gext = g_ext; cb.ldge = C; cb.gld = g_ld; cb.z = z; cb.ldz = C; cb.h = hsave;
+  cb.es3 = s->es3; cb.ga3 = ga3; cb.gz = gz; cb.ldgz = C; cb.part = tail; cb.HW = HW; cb.C = C; cb.Cout = Cout;
+  cb.additive = s->additive;
+  NFK_TRY(launch_coupling_bwd(cb, B, st));
+
+  // conv3 (block.4): wgrad then dgrad
+  WgradArgs w3{};
+  w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
+  w3.B = B; w3.H = H; w3.W = W; w3.out = wslab; w3.slab_stride = (long)Cout * 9 * hid;
+  NFK_TRY(wgrad_gemm(w3, L.S3w, st));
+  NFK_TRY(wgrad_finalize(wslab, L.S3w, w3.slab_stride, Cout, hid, 9, g->g_w3, st));
+  ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD);
+  d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
+  NFK_TRY(conv_gemm(d3, st));
+
+  // conv2 (block.2)
+  WgradArgs w2{};
+  w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
+  w2.B = B; w2.H = H; w2.W = W; w2.out = wslab; w2.slab_stride = (long)hid * hid;
+  NFK_TRY(wgrad_gemm(w2, L.S2w, st));
+  NFK_TRY(wgrad_finalize(wslab, L.S2w, w2.slab_stride, hid, hid, 1, g->g_w2, st));
+  ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD);
+  d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
+  NFK_TRY(conv_gemm(d2, st));
+
+  // conv1 (block.0)
+  WgradArgs w1{};
+  w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = z; w1.ldq = C; w1.Cq = Ch; w1.taps = 9;
+  w1.B = B; w1.H = H; w1.W = W; w1.out = wslab; w1.slab_stride = (long)hid * 9 * Ch;
+  NFK_TRY(wgrad_gemm(w1, L.S1w, st));
+  NFK_TRY(wgrad_finalize(wslab, L.S1w, w1.slab_stride, hid, Ch, 9, g->g_w1, st));
+  ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW);
+  NFK_TRY(conv_gemm(d1a, st));
+
+  nfk_small_grad_args sg{};
+  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb; sg.mb2 = L.mb; sg.B = B;
+  sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
+  sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
+  sg.g_l3 = g->g_l3;
+  NFK_TRY(launch_small_grads(sg, st));
+
+  // actnorm + permutation backward: g_x = Wf^T g_z, partial (gWf, gcf) for nfk_prep_bwd
+  ChanMixArgs m{};
+  m.x = gz; m.ldx = C; m.Wm = s->Wf; m.cv = nullptr; m.z = g_x; m.ldz = C; m.M = M; m.C = C; m.trans = 1;
+  m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = L.S1; m.slab_stride = (long)M * Ch;
+  m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
+  return launch_chanmix(m, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// Split2d composites
+// ------------------------------------------------------------------------------------------
+int nfk_split2d_fwd(const nfk_split2d* s, const float* x, const float* ld_in, float* z1out, float* hsave,
+                    float* ws, float* ld_out, void* stream) {
+  hipStream_t st = S_(stream);
+  const int M = s->B * s->H * s->W, Ch = s->C / 2;
+  ConvGemmArgs c = conv_args(x, s->C, s->B, s->H, s->W, Ch, 9, s->wt, s->C, ws, s->C, EPI_RAW);
+  NFK_TRY(conv_gemm(c, st));
+  SplitArgs a{};
+  a.a = ws; a.S = conv_splitk(M, s->C, 9 * Ch, EPI_RAW); a.slab_stride = (long)M * s->C;
+  a.bias = s->bias; a.es = s->es; a.x = x; a.ldx = s->C; a.z1out = z1out; a.hsave = hsave;
+  a.ld_in = ld_in; a.ld_out = ld_out; a.HW = s->H * s->W; a.C = s->C; a.has_ld = ld_out != nullptr;
+  return launch_split_fwd(a, s->B, st);
+}
+int nfk_split2d_inv(const nfk_split2d* s, const float* z1, const float* eps, float temperature, float* xout,
+                    float* ws, void* stream) {
+  hipStream_t st = S_(stream);
+  const int M = s->B * s->H * s->W, Ch = s->C / 2;
+  ConvGemmArgs c = conv_args(z1, Ch, s->B, s->H, s->W, Ch, 9, s->wt, s->C, ws, s->C, EPI_RAW);
+  NFK_TRY(conv_gemm(c, st));
+  SplitArgs a{};
+  a.a = ws; a.S = conv_splitk(M, s->C, 9 * Ch, EPI_RAW); a.slab_stride = (long)M * s->C;
+  a.bias = s->bias; a.es = s->es; a.x = z1; a.ldx = Ch; a.z1out = xout; a.HW = s->H * s->W; a.C = s->C;
+  a.eps = eps; a.temperature = temperature;
+  return launch_split_inv(a, s->B, st);
+}
+int nfk_split2d_bwd(const nfk_split2d* s, const float* x, const float* hsave, const float* g_z1,
+                    const float* g_ext, const float* g_ld, float* g_x, float* g_w, float* g_bias, float* g_logs,
+                    float* ws, void* stream) {
+  hipStream_t st = S_(stream);
+  const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, M = B * H * W;
+  const int Sd = conv_splitk(M, Ch, 9 * C, EPI_RAW), Sw = wgrad_splits(M, C, 9 * Ch);
+  float* ga = ws;
+  float* dslab = ga + align4((size_t)M * C);
+  float* tail = dslab + align4((size_t)Sd * M * Ch);
+  float* wslab = tail + align4((size_t)B * 2 * C);
+  SplitBwdArgs b{};
+  b.gld = g_ld; b.x = x; b.ldx = C; b.h = hsave; b.es = s->es; b.ga = ga; b.gx = g_x; b.ldgx = C; b.part = tail;
+  b.HW = H * W; b.C = C;
+  NFK_TRY(launch_split_bwd(b, B, st));
+  WgradArgs w{};
+  w.P = ga; w.ldp = C; w.NI = C; w.Q = x; w.ldq = C; w.Cq = Ch; w.taps = 9; w.B = B; w.H = H; w.W = W;
+  w.out = wslab; w.slab_stride = (long)C * 9 * Ch;
+  NFK_TRY(wgrad_gemm(w, Sw, st));
+  NFK_TRY(wgrad_finalize(wslab, Sw, w.slab_stride, C, Ch, 9, g_w, st));
+  ConvGemmArgs d = conv_args(ga, C, B, H, W, C, 9, s->wd, Ch, dslab, Ch, EPI_RAW);
+  NFK_TRY(conv_gemm(d, st));
+  NFK_TRY(launch_add_slabs(g_z1, Ch, g_ext, Ch, dslab, Sd, (long)M * Ch, g_x, C, M, Ch, st));
+  nfk_small_grad_args sg{};
+  sg.tail = tail; sg.B = B; sg.n3 = C; sg.g_bias3 = g_bias; sg.g_l3 = g_logs;
+  return launch_small_grads(sg, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// Device-side helpers shared by the nfk kernels (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nfk.h"
+
+
+
+
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace nfk {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum over the whole workgroup (blockDim.x multiple of 64, <= 1024).  Result valid in every
+// thread.  `scratch` must hold >= 16 floats.  Deterministic: fixed tree order.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += scratch[i];
+  return t;
+}
+
+__device__ __forceinline__ float sigmoidf(float t) { return 1.f / (1.f + __expf(-t)); }
+// log(sigmoid(t)) without cancellation: -log1p(exp(-t)) for t>=0, t - log1p(exp(t)) otherwise.
+__device__ __forceinline__ float log_sigmoidf(float t) {
+  return t >= 0.f ? -log1pf(expf(-t)) : t - log1pf(expf(t));
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#define NFK_LAUNCH_CHECK()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return NFK_ERR_LAUNCH; \
+  } while (0)
+
+}  // namespace nfk

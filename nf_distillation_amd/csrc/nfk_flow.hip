@@ -1,0 +1,809 @@
+// nfk flow kernels: the HBM-bound part of a Glow FlowStep on NHWC activations.
+//
+//   prep        : per-step parameter products, once per forward for ALL steps in one launch:
+//                 W = P(L+I)(U+diag(sign_s e^{log_s}))           models/layers.py:380-397
+//                 Wf = W diag(e^{logs}), cf = Wf bias  (ActNorm folded into the 1x1 conv,
+//                 models/layers.py:101-142 + :404-421), W^-1 by pivoted Gauss-Jordan instead of
+//                 three torch.inverse calls (:390-395), dlogdet = pixels (sum logs + sum log_s),
+//                 e^{logs} of the coupling net's ActNorms and e^{3 logs} of Conv2dZeros (:260).
+//   chanmix     : z = Wf x + cf per pixel  (ActNorm2d/1d + InvertibleConv1x1 / Permute2d)
+//   coupling    : affine/additive coupling tail + per-sample log-det (models/flows.py:157-169)
+//   squeeze     : space-to-depth (models/layers.py:32-61), NCHW boundary folded in
+//   split prior : Split2d Gaussian log-density (models/layers.py:293-313)
+//   top prior   : gaussian_likelihood + bits/dim (models/kd_flows.py:136-150)
+// plus the inverse and backward of each.  Log-det sums use one workgroup per sample with a
+// fixed-order wave/LDS tree (no atomics), so results are bitwise reproducible run to run.
+#include "nfk_internal.h"
+
+namespace nfk {
+
+// ==========================================================================================
+// small dense helpers on global scratch, executed by ONE workgroup
+// ==========================================================================================
+// C[n][n] = A * B   (opA/opB: 0 = as is, 1 = transposed)
+__device__ void blk_matmul(const float* A, int ta, const float* B, int tb, float* C, int n) {
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx % n;
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += (ta ? A[k * n + i] : A[i * n + k]) * (tb ? B[j * n + k] : B[k * n + j]);
+    C[idx] = s;
+  }
+  __syncthreads();
+}
+
+// In-place Gauss-Jordan inverse with partial pivoting of A (n x n) using aug[n][2n] scratch.
+// Returns log|det A| (valid in all threads).  sh must hold >= 4 floats/ints.
+__device__ float blk_inverse(const float* A, float* inv, float* aug, int n, float* sh) {
+  const int n2 = 2 * n;
+  for (int idx = threadIdx.x; idx < n * n2; idx += blockDim.x) {
+    const int i = idx / n2, j = idx % n2;
+    aug[idx] = j < n ? A[i * n + j] : (j - n == i ? 1.f : 0.f);
+  }
+  __syncthreads();
+  float logdet = 0.f;
+  for (int k = 0; k < n; ++k) {
+    if (threadIdx.x == 0) {
+      int best = k;
+      float bv = fabsf(aug[k * n2 + k]);
+      for (int r = k + 1; r < n; ++r) {
+        const float v = fabsf(aug[r * n2 + k]);
+        if (v > bv) { bv = v; best = r; }
+      }
+      reinterpret_cast<int*>(sh)[0] = best;
+    }
+    __syncthreads();
+    const int piv = reinterpret_cast<int*>(sh)[0];
+    if (piv != k) {
+      for (int j = threadIdx.x; j < n2; j += blockDim.x) {
+        const float t = aug[k * n2 + j];
+        aug[k * n2 + j] = aug[piv * n2 + j];
+        aug[piv * n2 + j] = t;
+      }
+    }
+    __syncthreads();
+    const float d = aug[k * n2 + k];
+    logdet += logf(fabsf(d));
+    __syncthreads();
+    const float rd = 1.f / d;
+    for (int j = threadIdx.x; j < n2; j += blockDim.x) aug[k * n2 + j] *= rd;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * n2; idx += blockDim.x) {
+      const int i = idx / n2, j = idx % n2;
+      if (i == k) continue;
+      // column k of row i is needed by every j of that row: read before any thread overwrites it
+      // (it is overwritten only by j == k, which is handled after the barrier below)
+      if (j != k) aug[idx] -= aug[i * n2 + k] * aug[k * n2 + j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      if (i != k) aug[i * n2 + k] = 0.f;
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) inv[idx] = aug[(idx / n) * n2 + n + idx % n];
+  __syncthreads();
+  return logdet;
+}
+
+// scratch layout inside PrepDesc::scratch (floats): T0,T1,T2 [C*C] each, AUG [2*C*C]
+__device__ void build_W(const PrepDesc& d, float* W, float* T0, float* T1, float* sh) {
+  const int C = d.C;
+  if (d.perm_kind == PERM_LU) {
+    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
+      const int i = idx / C, j = idx % C;
+      T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
+      T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
+    }
+    __syncthreads();
+    blk_matmul(T0, 0, T1, 0, W, C);        // W <- L U   (temporarily)
+    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) T0[idx] = W[idx];
+    __syncthreads();
+    blk_matmul(d.p, 0, T0, 0, W, C);       // W <- P (L U)
+  } else if (d.perm_kind == PERM_DENSE) {
+    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) W[idx] = d.weight[idx];
+    __syncthreads();
+  } else {  // channel gather: z[:, o] = y[:, idx[o]]
+    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x)
+      W[idx] = (idx % C == d.perm_idx[idx / C]) ? 1.f : 0.f;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ descs, int want_inverse) {
+  __shared__ float sh[32];
+  const PrepDesc d = descs[blockIdx.x];
+  const int C = d.C, CC = C * C;
+  float* W = d.scratch;
+  float* T0 = W + CC;
+  float* T1 = T0 + CC;
+  float* AUG = T1 + CC;
+  if (C > 0) {
+  build_W(d, W, T0, T1, sh);
+
+  // sums of logs / log_s
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    s += d.an_logs[c];
+    if (d.perm_kind == PERM_LU) s += d.log_s[c];
+  }
+  s = block_sum(s, sh);
+  float logabsdet = 0.f;
+  if (d.perm_kind == PERM_DENSE || want_inverse) {
+    logabsdet = blk_inverse(W, T0, AUG, C, sh);  // T0 <- W^-1
+    if (d.perm_kind == PERM_DENSE) s += logabsdet;
+  }
+  if (threadIdx.x == 0) d.dld[0] = s * (float)d.pixels;
+
+  // forward products.  2-D: z = W y ; 1-D: z = y @ W  (y = (x + b) e^{logs})
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+    const int o = idx / C, c = idx % C;
+    const float w = d.is_1d ? W[c * C + o] : W[idx];
+    d.Wf[idx] = w * expf(d.an_logs[c]);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float t = 0.f;
+    for (int c = 0; c < C; ++c) t += d.Wf[o * C + c] * d.an_bias[c];
+    d.cf[o] = t;
+  }
+  if (want_inverse && d.Wi) {
+    // x_c = e^{-logs_c} sum_o Winv[c][o] z_o - b_c   (1-D: Winv[o][c])
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+      const int c = idx / C, o = idx % C;
+      const float w = d.is_1d ? T0[o * C + c] : T0[idx];
+      d.Wi[idx] = w * expf(-d.an_logs[c]);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) d.ci[c] = -d.an_bias[c];
+  }
+  }  // C > 0
+  // coupling-net scales
+  for (int i = threadIdx.x; i < d.n1; i += blockDim.x) d.es1[i] = expf(d.l1[i]);
+  for (int i = threadIdx.x; i < d.n2; i += blockDim.x) d.es2[i] = expf(d.l2[i]);
+  for (int i = threadIdx.x; i < d.n3; i += blockDim.x) d.es3[i] = expf(3.f * d.l3[i]);
+}
+
+// Backward of prep: chain (gWf, gcf, G = sum_b g_logdet[b]) to the raw parameters; accumulates.
+//   part: [nparts][C*C + C] partial sums of  gWf[o][c] = sum_m gz[m][o] x[m][c],  gcf[o] = sum_m gz[m][o]
+__global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
+                                                       const PrepGrad* __restrict__ grads,
+                                                       const float* __restrict__ gld, int B) {
+  __shared__ float sh[32];
+  const PrepDesc d = descs[blockIdx.x];
+  const PrepGrad g = grads[blockIdx.x];
+  const int C = d.C, CC = C * C;
+  if (C == 0) return;
+  float* W = d.scratch;
+  float* T0 = W + CC;
+  float* T1 = T0 + CC;
+  float* AUG = T1 + CC;   // 2*CC floats: use as two more matrices
+  float* GW = AUG;
+  float* T2 = AUG + CC;
+
+  float G = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) G += gld[b];
+  G = block_sum(G, sh) * (float)d.pixels;
+
+  // reduce partials (fixed order): GWf -> T0 ; gcf -> T1[0..C)
+  for (int idx = threadIdx.x; idx < CC + C; idx += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < g.nparts; ++p) s += g.part[(long)p * (CC + C) + idx];
+    if (idx < CC) T0[idx] = s; else T1[idx - CC] = s;
+  }
+  __syncthreads();
+  // g_bias[c] = sum_o Wf[o][c] gcf[o];  gWf_tot = gWf + gcf b^T
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int o = 0; o < C; ++o) t += d.Wf[o * C + c] * T1[o];
+    g.g_an_bias[c] += t;
+  }
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) T0[idx] += T1[idx / C] * d.an_bias[idx % C];
+  __syncthreads();
+  // g_logs[c] = sum_o gWf_tot[o][c] Wf[o][c] + G ;  gW (in W's own index convention) -> GW
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int o = 0; o < C; ++o) t += T0[o * C + c] * d.Wf[o * C + c];
+    g.g_an_logs[c] += t + G;
+  }
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+    const int o = idx / C, c = idx % C;
+    const float v = T0[idx] * expf(d.an_logs[c]);
+    if (d.is_1d) GW[c * C + o] = v; else GW[idx] = v;
+  }
+  __syncthreads();
+  if (d.perm_kind == PERM_LU) {
+    // L -> T0, U -> T1
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+      const int i = idx / C, j = idx % C;
+      T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
+      T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
+    }
+    __syncthreads();
+    blk_matmul(d.p, 1, GW, 0, T2, C);   // T2 = P^T gW
+    blk_matmul(T2, 0, T1, 1, W, C);     // W  = P^T gW U^T   -> g_L
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x)
+      if (idx / C > idx % C) g.g_lower[idx] += W[idx];
+    __syncthreads();
+    blk_matmul(T0, 1, T2, 0, W, C);     // W = L^T P^T gW     -> g_U
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+      const int i = idx / C, j = idx % C;
+      if (i < j) g.g_upper[idx] += W[idx];
+      else if (i == j) g.g_log_s[i] += W[idx] * d.sign_s[i] * expf(d.log_s[i]) + G;
+    }
+  }
+}
+
+// Dense-weight variant needs GW after the inverse; done in a second tiny kernel to keep scratch small.
+__global__ void __launch_bounds__(256) prep_bwd_dense_kernel(const PrepDesc* __restrict__ descs,
+                                                             const PrepGrad* __restrict__ grads,
+                                                             const float* __restrict__ gld, int B) {
+  __shared__ float sh[32];
+  const PrepDesc d = descs[blockIdx.x];
+  if (d.perm_kind != PERM_DENSE) return;
+  const PrepGrad g = grads[blockIdx.x];
+  const int C = d.C, CC = C * C;
+  float* W = d.scratch;
+  float* T0 = W + CC;
+  float* T1 = T0 + CC;
+  float* AUG = T1 + CC;
+  float G = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) G += gld[b];
+  G = block_sum(G, sh) * (float)d.pixels;
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) W[idx] = d.weight[idx];
+  __syncthreads();
+  blk_inverse(W, T0, AUG, C, sh);  // T0 = W^-1
+  // recompute gWf_tot from partials
+  for (int idx = threadIdx.x; idx < CC + C; idx += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < g.nparts; ++p) s += g.part[(long)p * (CC + C) + idx];
+    if (idx < CC) AUG[idx] = s; else T1[idx - CC] = s;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+    const int o = idx / C, c = idx % C;
+    const float v = (AUG[idx] + T1[o] * d.an_bias[c]) * expf(d.an_logs[c]);
+    // d log|det W| / dW = W^-T
+    if (d.is_1d) g.g_weight[c * C + o] += v + G * T0[o * C + c];
+    else g.g_weight[idx] += v + G * T0[c * C + o];
+  }
+}
+
+// ==========================================================================================
+// chanmix:  z[m][o] = sum_c Wm[o][c] x[m][c] + cv[o]      (trans: uses Wm[c][o], no cv)
+// ==========================================================================================
+constexpr int CM_TP = 64;  // pixels per workgroup
+
+
+__global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C, Cp = (C + 3) & ~3, XS = C + 1;
+  float* Wl = smem;                 // [C][Cp]  stored [in][out]
+  float* Xl = Wl + C * Cp;          // [TP][C+1]
+  float* Gl = Xl + CM_TP * XS;      // [TP][C+1] (backward: x_in tile)
+  const int m0 = blockIdx.x * CM_TP;
+  for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
+    const int r = idx / C, q = idx % C;  // Wm[r][q]
+    if (a.trans) Wl[r * Cp + q] = a.Wm[idx];      // in = r (rows of Wm), out = q
+    else Wl[q * Cp + r] = a.Wm[idx];               // in = q, out = r
+  }
+  for (int idx = threadIdx.x; idx < CM_TP * C; idx += blockDim.x) {
+    const int p = idx / C, c = idx % C, m = m0 + p;
+    float v = 0.f;
+    if (m < a.M) {
+      if (a.ga && c < a.Ch) {
+        v = a.ga[(long)m * a.lda + c];
+        if (a.gext) v += a.gext[(long)m * a.ldge + c];
+        for (int s = 0; s < a.S; ++s) v += a.slab[s * a.slab_stride + (long)m * a.Ch + c];
+      } else {
+        v = a.x[(long)m * a.ldx + c];
+      }
+    }
+    Xl[p * XS + c] = v;
+    if (a.part) Gl[p * XS + c] = m < a.M ? a.xin[(long)m * a.ldxin + c] : 0.f;
+  }
+  __syncthreads();
+  const int p = threadIdx.x & (CM_TP - 1), og = threadIdx.x / CM_TP, ngroups = blockDim.x / CM_TP;
+  const int m = m0 + p;
+  for (int o = og * 4; o < C; o += ngroups * 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (a.cv)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (o + r < C) acc[r] = a.cv[o + r];
+    for (int c = 0; c < C; ++c) {
+      const float xv = Xl[p * XS + c];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp + o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+    }
+    if (m < a.M) {
+      float* zp = a.z + (long)m * a.ldz + o;
+      if (o + 3 < C && (a.ldz & 3) == 0) *reinterpret_cast<f32x4*>(zp) = acc;
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < C) zp[r] = acc[r];
+    }
+  }
+  if (a.part) {
+    float* part = a.part + (long)blockIdx.x * (C * C + C);
+    for (int idx = threadIdx.x; idx < C * C + C; idx += blockDim.x) {
+      float s = 0.f;
+      if (idx < C * C) {
+        const int o = idx / C, c = idx % C;
+        for (int q = 0; q < CM_TP; ++q) s += Xl[q * XS + o] * Gl[q * XS + c];
+      } else {
+        const int o = idx - C * C;
+        for (int q = 0; q < CM_TP; ++q) s += Xl[q * XS + o];
+      }
+      part[idx] = s;
+    }
+  }
+}
+
+// ==========================================================================================
+// coupling tail (affine / additive), one workgroup per sample
+// ==========================================================================================
+
+__device__ __forceinline__ float slab_sum(const float* a3, int S, long stride, long off) {
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += a3[s * stride + off];
+  return v;
+}
+
+__global__ void __launch_bounds__(256) coupling_fwd_kernel(CouplingArgs a) {
+  __shared__ float sh[32];
+  const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
+  const long mb = (long)b * a.HW;
+  float ls = 0.f;
+  for (int idx = threadIdx.x; idx < a.HW * C2; idx += blockDim.x) {
+    const int p = idx / C2, j = idx % C2;
+    const long m = mb + p;
+    const float z2 = a.z[m * a.ldz + Ch + j];
+    float out;
+    if (a.additive) {
+      const float h = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + j) + a.bias3[j]) * a.es3[j];
+      if (a.hsave) a.hsave[m * a.Cout + j] = h;
+      out = z2 + h;
+    } else {
+      const float sh_ = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + 2 * j) + a.bias3[2 * j]) * a.es3[2 * j];
+      const float sr = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + 2 * j + 1) + a.bias3[2 * j + 1]) * a.es3[2 * j + 1];
+      if (a.hsave) { a.hsave[m * a.Cout + 2 * j] = sh_; a.hsave[m * a.Cout + 2 * j + 1] = sr; }
+      const float t = sr + 2.f;
+      out = (z2 + sh_) * sigmoidf(t);
+      ls += log_sigmoidf(t);
+    }
+    a.zout[m * a.ldo + Ch + j] = out;
+  }
+  for (int idx = threadIdx.x; idx < a.HW * Ch; idx += blockDim.x) {
+    const int p = idx / Ch, j = idx % Ch;
+    a.zout[(mb + p) * a.ldo + j] = a.z[(mb + p) * a.ldz + j];
+  }
+  if (a.has_ld) {
+    ls = block_sum(ls, sh);
+    if (threadIdx.x == 0) a.ld_out[b] = a.ld_in[b] + a.dld[0] + ls;
+  }
+}
+
+// inverse: given the step OUTPUT y = (z1 | z2'), recover the mixed z = (z1 | z2)
+__global__ void __launch_bounds__(256) coupling_inv_kernel(CouplingArgs a) {
+  __shared__ float sh[32];
+  const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
+  const long mb = (long)b * a.HW;
+  float ls = 0.f;
+  for (int idx = threadIdx.x; idx < a.HW * C2; idx += blockDim.x) {
+    const int p = idx / C2, j = idx % C2;
+    const long m = mb + p;
+    const float y2 = a.z[m * a.ldz + Ch + j];
+    float out;
+    if (a.additive) {
+      out = y2 - (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + j) + a.bias3[j]) * a.es3[j];
+    } else {
+      const float sh_ = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + 2 * j) + a.bias3[2 * j]) * a.es3[2 * j];
+      const float sr = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + 2 * j + 1) + a.bias3[2 * j + 1]) * a.es3[2 * j + 1];
+      const float t = sr + 2.f;
+      out = y2 * (1.f + expf(-t)) - sh_;   // y2 / sigmoid(t) - shift
+      ls += log_sigmoidf(t);
+    }
+    a.zout[m * a.ldo + Ch + j] = out;
+  }
+  for (int idx = threadIdx.x; idx < a.HW * Ch; idx += blockDim.x) {
+    const int p = idx / Ch, j = idx % Ch;
+    a.zout[(mb + p) * a.ldo + j] = a.z[(mb + p) * a.ldz + j];
+  }
+  if (a.has_ld) {
+    ls = block_sum(ls, sh);
+    if (threadIdx.x == 0) a.ld_out[b] = a.ld_in[b] - a.dld[0] - ls;
+  }
+}
+
+// backward of the coupling tail
+
+__global__ void __launch_bounds__(256) coupling_bwd_kernel(CouplingBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [G][4][C2] per-group column sums
+  const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
+  const long mb = (long)b * a.HW;
+  const float gl = a.gld ? a.gld[b] : 0.f;
+  // thread (g, j): column j, pixels g, g+G, ...; column sums reduced over g in fixed order via LDS
+  const int G = blockDim.x / C2 > 0 ? blockDim.x / C2 : 1;
+  const int j = threadIdx.x % C2, g = threadIdx.x / C2;
+  float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
+  if (g < G && (int)threadIdx.x < G * C2) {
+    for (int p = g; p < a.HW; p += G) {
+      const long m = mb + p;
+      float g2 = a.gout[m * a.ldg + Ch + j];
+      if (a.gext) g2 += a.gext[m * a.ldge + Ch + j];
+      if (a.additive) {
+        const float h = a.h[m * a.Cout + j];
+        a.gz[m * a.ldgz + Ch + j] = g2;
+        const float ga = g2 * a.es3[j];
+        a.ga3[m * a.Cout + j] = ga;
+        sb0 += ga; sl0 += g2 * h;
+      } else {
+        const float shf = a.h[m * a.Cout + 2 * j], sr = a.h[m * a.Cout + 2 * j + 1];
+        const float sc = sigmoidf(sr + 2.f);
+        const float z2 = a.z[m * a.ldz + Ch + j];
+        const float gshift = g2 * sc;
+        // d/dsr [ (z2+shift) sc ] = (z2+shift) sc (1-sc);  d/dsr log sc = 1 - sc
+        const float gsr = g2 * (z2 + shf) * sc * (1.f - sc) + gl * (1.f - sc);
+        a.gz[m * a.ldgz + Ch + j] = gshift;
+        const float ga0 = gshift * a.es3[2 * j], ga1 = gsr * a.es3[2 * j + 1];
+        a.ga3[m * a.Cout + 2 * j] = ga0;
+        a.ga3[m * a.Cout + 2 * j + 1] = ga1;
+        sb0 += ga0; sl0 += gshift * shf; sb1 += ga1; sl1 += gsr * sr;
+      }
+    }
+    float* row = acc + (long)g * 4 * C2;
+    row[j] = sb0; row[C2 + j] = sl0; row[2 * C2 + j] = sb1; row[3 * C2 + j] = sl1;
+  }
+  __syncthreads();
+  for (int jj = threadIdx.x; jj < C2; jj += blockDim.x) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int gg = 0; gg < G; ++gg) {
+      const float* row = acc + (long)gg * 4 * C2;
+      t0 += row[jj]; t1 += row[C2 + jj]; t2 += row[2 * C2 + jj]; t3 += row[3 * C2 + jj];
+    }
+    float* part = a.part + (long)b * 2 * a.Cout;
+    if (a.additive) { part[jj] = t0; part[a.Cout + jj] = 3.f * t1; }
+    else {
+      part[2 * jj] = t0; part[2 * jj + 1] = t2;
+      part[a.Cout + 2 * jj] = 3.f * t1; part[a.Cout + 2 * jj + 1] = 3.f * t3;
+    }
+  }
+}
+
+// ==========================================================================================
+// squeeze / unsqueeze (space-to-depth by 2)
+// ==========================================================================================
+// NCHW input (model boundary) -> NHWC squeezed; optional in-place dequantisation noise.
+__global__ void squeeze_nchw_kernel(float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
+                                    int B, int C, int H, int W) {
+  const long total = (long)B * C * H * W;
+  const int Ho = H / 2, Wo = W / 2;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int w = t % W; long r = t / W;
+    const int h = r % H; r /= H;
+    const int c = r % C; const int b = r / C;
+    float v = x[t];
+    if (noise) { v += noise[t]; x[t] = v; }
+    const int co = c * 4 + (h & 1) * 2 + (w & 1);
+    out[(((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * (4 * C) + co] = v;
+  }
+}
+// NHWC -> NHWC squeezed
+__global__ void squeeze_nhwc_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int B, int C,
+                                    int H, int W) {
+  const int Ho = H / 2, Wo = W / 2, Co = 4 * C;
+  const long total = (long)B * Ho * Wo * Co;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int co = t % Co; long r = t / Co;
+    const int wo = r % Wo; r /= Wo;
+    const int ho = r % Ho; const int b = r / Ho;
+    const int c = co >> 2, fh = (co >> 1) & 1, fw = co & 1;
+    out[t] = x[(((long)b * H + 2 * ho + fh) * W + 2 * wo + fw) * ldx + c];
+  }
+}
+// NHWC squeezed -> NHWC unsqueezed (also the backward of squeeze_nhwc)
+__global__ void unsqueeze_nhwc_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int C, int H,
+                                      int W) {  // (C,H,W) = UNsqueezed dims
+  const int Ho = H / 2, Wo = W / 2, Co = 4 * C;
+  const long total = (long)B * H * W * C;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int c = t % C; long r = t / C;
+    const int w = r % W; r /= W;
+    const int h = r % H; const int b = r / H;
+    out[t] = y[(((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * Co + c * 4 + (h & 1) * 2 + (w & 1)];
+  }
+}
+// NHWC squeezed -> NCHW unsqueezed (model boundary of the reverse pass / grad wrt input image)
+__global__ void unsqueeze_to_nchw_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int C, int H,
+                                         int W) {
+  const int Ho = H / 2, Wo = W / 2, Co = 4 * C;
+  const long total = (long)B * C * H * W;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int w = t % W; long r = t / W;
+    const int h = r % H; r /= H;
+    const int c = r % C; const int b = r / C;
+    out[t] = y[(((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * Co + c * 4 + (h & 1) * 2 + (w & 1)];
+  }
+}
+
+// ==========================================================================================
+// Split2d prior tail
+// ==========================================================================================
+constexpr float LN_2PI = 1.8378770664093453f;
+
+__global__ void __launch_bounds__(256) split_fwd_kernel(SplitArgs a) {
+  __shared__ float sh[32];
+  const int b = blockIdx.x, Ch = a.C / 2;
+  const long mb = (long)b * a.HW;
+  float lp = 0.f;
+  for (int idx = threadIdx.x; idx < a.HW * Ch; idx += blockDim.x) {
+    const int p = idx / Ch, j = idx % Ch;
+    const long m = mb + p;
+    const float mean = (slab_sum(a.a, a.S, a.slab_stride, m * a.C + 2 * j) + a.bias[2 * j]) * a.es[2 * j];
+    const float logs = (slab_sum(a.a, a.S, a.slab_stride, m * a.C + 2 * j + 1) + a.bias[2 * j + 1]) * a.es[2 * j + 1];
+    if (a.hsave) { a.hsave[m * a.C + 2 * j] = mean; a.hsave[m * a.C + 2 * j + 1] = logs; }
+    const float d = a.x[m * a.ldx + Ch + j] - mean;
+    lp += -0.5f * (2.f * logs + d * d * expf(-2.f * logs) + LN_2PI);
+    a.z1out[m * Ch + j] = a.x[m * a.ldx + j];
+  }
+  if (a.has_ld) {
+    lp = block_sum(lp, sh);
+    if (threadIdx.x == 0) a.ld_out[b] = a.ld_in[b] + lp;
+  }
+}
+// inverse: x = z1 [M][Ch] (ldx = Ch); writes full [M][C] = (z1 | mean + e^{logs} T eps) into z1out
+__global__ void __launch_bounds__(256) split_inv_kernel(SplitArgs a) {
+  const int b = blockIdx.x, Ch = a.C / 2;
+  const long mb = (long)b * a.HW;
+  for (int idx = threadIdx.x; idx < a.HW * Ch; idx += blockDim.x) {
+    const int p = idx / Ch, j = idx % Ch;
+    const long m = mb + p;
+    const float mean = (slab_sum(a.a, a.S, a.slab_stride, m * a.C + 2 * j) + a.bias[2 * j]) * a.es[2 * j];
+    const float logs = (slab_sum(a.a, a.S, a.slab_stride, m * a.C + 2 * j + 1) + a.bias[2 * j + 1]) * a.es[2 * j + 1];
+    const float e = a.eps ? a.eps[m * Ch + j] : 0.f;
+    a.z1out[m * a.C + j] = a.x[m * a.ldx + j];
+    a.z1out[m * a.C + Ch + j] = mean + expf(logs) * a.temperature * e;
+  }
+}
+
+__global__ void __launch_bounds__(256) split_bwd_kernel(SplitBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int b = blockIdx.x, Ch = a.C / 2;
+  const long mb = (long)b * a.HW;
+  const float gl = a.gld[b];
+  const int G = blockDim.x / Ch > 0 ? blockDim.x / Ch : 1;
+  const int j = threadIdx.x % Ch, g = threadIdx.x / Ch;
+  if (g < G && (int)threadIdx.x < G * Ch) {
+    float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
+    for (int p = g; p < a.HW; p += G) {
+      const long m = mb + p;
+      const float mean = a.h[m * a.C + 2 * j], logs = a.h[m * a.C + 2 * j + 1];
+      const float d = a.x[m * a.ldx + Ch + j] - mean, iv = expf(-2.f * logs);
+      const float gmean = gl * d * iv, glogs = gl * (d * d * iv - 1.f);
+      a.gx[m * a.ldgx + Ch + j] = -gmean;
+      const float ga0 = gmean * a.es[2 * j], ga1 = glogs * a.es[2 * j + 1];
+      a.ga[m * a.C + 2 * j] = ga0;
+      a.ga[m * a.C + 2 * j + 1] = ga1;
+      sb0 += ga0; sl0 += gmean * mean; sb1 += ga1; sl1 += glogs * logs;
+    }
+    float* row = acc + (long)g * 4 * Ch;
+    row[j] = sb0; row[Ch + j] = sl0; row[2 * Ch + j] = sb1; row[3 * Ch + j] = sl1;
+  }
+  __syncthreads();
+  for (int jj = threadIdx.x; jj < Ch; jj += blockDim.x) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int gg = 0; gg < G; ++gg) {
+      const float* row = acc + (long)gg * 4 * Ch;
+      t0 += row[jj]; t1 += row[Ch + jj]; t2 += row[2 * Ch + jj]; t3 += row[3 * Ch + jj];
+    }
+    float* part = a.part + (long)b * 2 * a.C;
+    part[2 * jj] = t0; part[2 * jj + 1] = t2;
+    part[a.C + 2 * jj] = 3.f * t1; part[a.C + 2 * jj + 1] = 3.f * t3;
+  }
+}
+
+// out[m][c] = g[m][c] (+ gext[m][c]) + sum_s slab[s][m][c]   for c < Ch  (first-half grads)
+__global__ void add_slabs_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ gext, int ldge,
+                                 const float* __restrict__ slab, int S, long slab_stride, float* __restrict__ out,
+                                 int ldo, long M, int Ch) {
+  const long total = M * Ch;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long m = t / Ch; const int c = t % Ch;
+    float v = g ? g[m * ldg + c] : 0.f;
+    if (gext) v += gext[m * ldge + c];
+    for (int s = 0; s < S; ++s) v += slab[s * slab_stride + t];
+    out[m * ldo + c] = v;
+  }
+}
+
+// ==========================================================================================
+// top prior: objective = logdet + sum log N(z; mean, e^{logs}); bits/dim
+// ==========================================================================================
+__global__ void __launch_bounds__(256) prior_fwd_kernel(PriorArgs a) {
+  __shared__ float sh[32];
+  const int b = blockIdx.x;
+  const float* ph = a.ph + b * a.ph_bstride;
+  float lp = 0.f;
+  for (int idx = threadIdx.x; idx < a.HW * a.C; idx += blockDim.x) {
+    const int p = idx / a.C, c = idx % a.C;
+    const float mean = ph[(long)c * a.HW + p], logs = ph[(long)(a.C + c) * a.HW + p];
+    const float d = a.z[((long)b * a.HW + p) * a.ldz + c] - mean;
+    lp += -0.5f * (2.f * logs + d * d * expf(-2.f * logs) + LN_2PI);
+  }
+  lp = block_sum(lp, sh);
+  if (threadIdx.x == 0) {
+    const float obj = a.ld[b] + lp;
+    a.objective[b] = obj;
+    a.bpd[b] = -obj * a.bpd_scale;
+  }
+}
+__global__ void __launch_bounds__(256) prior_bwd_kernel(PriorBwdArgs a) {
+  const int b = blockIdx.x;
+  const float* ph = a.ph + b * a.ph_bstride;
+  const float gobj = -a.gbpd[b] * a.bpd_scale;
+  if (threadIdx.x == 0) a.gld[b] = gobj;
+  for (int idx = threadIdx.x; idx < a.HW * a.C; idx += blockDim.x) {
+    const int p = idx / a.C, c = idx % a.C;
+    const float mean = ph[(long)c * a.HW + p], logs = ph[(long)(a.C + c) * a.HW + p];
+    const float iv = expf(-2.f * logs), d = a.z[((long)b * a.HW + p) * a.ldz + c] - mean;
+    a.gz[((long)b * a.HW + p) * a.ldgz + c] = -gobj * d * iv;
+    if (a.gph) {
+      a.gph[((long)b * 2 * a.C + c) * a.HW + p] = gobj * d * iv;
+      a.gph[((long)b * 2 * a.C + a.C + c) * a.HW + p] = gobj * (d * d * iv - 1.f);
+    }
+  }
+}
+
+// Finalise the small per-channel parameter gradients of one coupling net (accumulates):
+//   colsum layout from conv_gemm EPI_DGRAD: [mblocks][2][N] = (sum acc*h , sum masked*scale)
+//   tail layout from coupling_bwd / split_bwd: [B][2][Cout] = (sum g_a3, 3 sum g_h h)
+__global__ void small_grads_kernel(SmallGradArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n1) {
+    float dl = 0.f, db = 0.f;
+    for (int i = 0; i < a.mb1; ++i) { dl += a.col1[((long)i * 2) * a.n1 + t]; db += a.col1[((long)i * 2 + 1) * a.n1 + t]; }
+    a.g_l1[t] += dl; a.g_b1[t] += db;
+  }
+  if (t < a.n2) {
+    float dl = 0.f, db = 0.f;
+    for (int i = 0; i < a.mb2; ++i) { dl += a.col2[((long)i * 2) * a.n2 + t]; db += a.col2[((long)i * 2 + 1) * a.n2 + t]; }
+    a.g_l2[t] += dl; a.g_b2[t] += db;
+  }
+  if (t < a.n3) {
+    float db = 0.f, dl = 0.f;
+    for (int i = 0; i < a.B; ++i) { db += a.tail[((long)i * 2) * a.n3 + t]; dl += a.tail[((long)i * 2 + 1) * a.n3 + t]; }
+    a.g_bias3[t] += db; a.g_l3[t] += dl;
+  }
+}
+
+// ==========================================================================================
+// host launchers
+// ==========================================================================================
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st) {
+  if (nsteps <= 0) return NFK_OK;
+  hipLaunchKernelGGL(prep_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, want_inverse);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
+                    int any_dense, hipStream_t st) {
+  if (nsteps <= 0) return NFK_OK;
+  hipLaunchKernelGGL(prep_bwd_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, grads_dev, gld, B);
+  NFK_LAUNCH_CHECK();
+  if (any_dense) {
+    hipLaunchKernelGGL(prep_bwd_dense_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, grads_dev, gld, B);
+    NFK_LAUNCH_CHECK();
+  }
+  return NFK_OK;
+}
+
+int launch_chanmix(const ChanMixArgs& a, hipStream_t st) {
+  if (a.M <= 0) return NFK_OK;
+  const int C = a.C, Cp = (C + 3) & ~3;
+  const size_t lds = (size_t)(C * Cp + 2 * CM_TP * (C + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return NFK_ERR_ARG;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chanmix_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(chanmix_kernel, dim3(ceil_div(a.M, CM_TP)), dim3(256), lds, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int chanmix_blocks(int M) { return ceil_div(M, CM_TP); }
+
+int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3(B), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(coupling_inv_kernel, dim3(B), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st) {
+  {
+    const int C2 = a.C - a.C / 2;
+    if (C2 > 256) return NFK_ERR_ARG;
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(B), dim3(256), (size_t)(256 / C2) * 4 * C2 * sizeof(float), st, a);
+  }
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_squeeze_nchw(float* x, const float* noise, float* out, int B, int C, int H, int W, hipStream_t st) {
+  if ((H | W) & 1) return NFK_ERR_ARG;
+  hipLaunchKernelGGL(squeeze_nchw_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, x, noise, out,
+                     B, C, H, W);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_squeeze_nhwc(const float* x, int ldx, float* out, int B, int C, int H, int W, hipStream_t st) {
+  if ((H | W) & 1) return NFK_ERR_ARG;
+  hipLaunchKernelGGL(squeeze_nhwc_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, x, ldx, out,
+                     B, C, H, W);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st) {
+  if ((H | W) & 1) return NFK_ERR_ARG;
+  if (to_nchw)
+    hipLaunchKernelGGL(unsqueeze_to_nchw_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, y, out,
+                       B, C, H, W);
+  else
+    hipLaunchKernelGGL(unsqueeze_nhwc_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, y, out, B,
+                       C, H, W);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_split_fwd(const SplitArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(split_fwd_kernel, dim3(B), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_split_inv(const SplitArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(split_inv_kernel, dim3(B), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_split_bwd(const SplitBwdArgs& a, int B, hipStream_t st) {
+  {
+    const int Ch = a.C / 2;
+    if (Ch > 256) return NFK_ERR_ARG;
+    hipLaunchKernelGGL(split_bwd_kernel, dim3(B), dim3(256), (size_t)(256 / Ch) * 4 * Ch * sizeof(float), st, a);
+  }
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_add_slabs(const float* g, int ldg, const float* gext, int ldge, const float* slab, int S,
+                     long slab_stride, float* out, int ldo, long M, int Ch, hipStream_t st) {
+  hipLaunchKernelGGL(add_slabs_kernel, dim3(ew_blocks(M * Ch)), dim3(256), 0, st, g, ldg, gext, ldge, slab, S,
+                     slab_stride, out, ldo, M, Ch);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_prior_fwd(const PriorArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(prior_fwd_kernel, dim3(B), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_prior_bwd(const PriorBwdArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(prior_bwd_kernel, dim3(B), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
+  int n = a.n1 > a.n2 ? a.n1 : a.n2;
+  if (a.n3 > n) n = a.n3;
+  if (n <= 0) return NFK_OK;
+  hipLaunchKernelGGL(small_grads_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+}  // namespace nfk

@@ -1,0 +1,572 @@
+// nfk GEMM engine: the coupling network's 3x3 / 1x1 convolutions as implicit GEMMs on the
+// gfx950 matrix cores (exact-f32 MFMA, v_mfma_f32_16x16x4_f32), NHWC activations.
+//
+// Replaces, for the reference's `Conv2d` / `Conv2dZeros` (models/layers.py:190-260) inside
+// `get_block_2d` (models/flows.py:25-34) and `Split2d.conv` (models/layers.py:296):
+//   forward   : ZeroPad2d + F.conv2d (+ ActNorm2d + ReLU fused as an epilogue)
+//   backward  : dgrad (a 3x3 SAME conv with flipped taps) and wgrad (reduction over pixels)
+//
+// One MFMA core serves all three: D[i][j] = sum_k A[i][k] * B[j][k] with both operand tiles
+// staged in LDS k-contiguous ([rows][32+4 pad]) and read with ds_read_b128, 4 MFMAs per read.
+//   conv/dgrad : A rows = output channels (repacked weights [N][Kp]), B rows = pixels (im2col
+//                gathered on the fly from NHWC, zero padding folded into the address predicate)
+//   wgrad      : A rows = channels of P, B rows = (tap,channel) of Q, k = pixel (transposed
+//                while staging)
+// The accumulator then holds 4 consecutive channels of one pixel per lane, so epilogues are
+// float4-wide and per-channel parameters load as float4.
+#include "nfk_internal.h"
+
+namespace nfk {
+
+constexpr int BK = 32;       // k-chunk per LDS stage
+constexpr int LS = BK + 4;   // LDS row stride (floats): 144 B keeps ds_read_b128 rows 16-B aligned
+
+
+
+// XCD-aware block remap (bijective): blocks that share an XCD (id % 8) get a contiguous range.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+template <int TN, int TM>
+__device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, const float* __restrict__ Bs,
+                                               int arow0, int brow0, int lane, f32x4 (&acc)[TN][TM]) {
+  const int r = lane & 15, kq = (lane >> 4) * 4;
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    f32x4 a[TN], b[TM];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+      a[t] = *reinterpret_cast<const f32x4*>(As + (arow0 + t * 16 + r) * LS + kh * 16 + kq);
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+      b[t] = *reinterpret_cast<const f32x4*>(Bs + (brow0 + t * 16 + r) * LS + kh * 16 + kq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tn][j], b[tm][j], acc[tn][tm], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv / dgrad kernel
+// ------------------------------------------------------------------------------------------
+template <int TN, int TM, int WN, int WM>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(ConvGemmArgs a) {
+  static_assert(WN * WM == 4, "256-thread workgroups");
+  constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
+  constexpr int WL = (BN * 8 + 255) / 256, XL = BM / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid % WN, wm = wid / WN;
+  const int nNB = (a.N + BN - 1) / BN, nMB = (a.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, nNB * nMB);
+  const int n0 = (bid % nNB) * BN, m0 = (bid / nNB) * BM;
+  const int HW = a.H * a.W;
+  const bool vec = ((a.Cin | a.ldx) & 3) == 0;
+
+  // split-K range (chunks of 32)
+  const int S = gridDim.y, z = blockIdx.y;
+  const int c_begin = (int)((long)a.nkchunks * z / S), c_end = (int)((long)a.nkchunks * (z + 1) / S);
+
+  // fixed per-thread load coordinates
+  const int lq = tid & 7, lr = tid >> 3;
+  int pix[XL], yx[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int m = m0 + lr + 32 * i;
+    if (m < a.M) {
+      const int rem = m % HW;
+      pix[i] = m;
+      yx[i] = ((rem / a.W) << 16) | (rem % a.W);
+    } else {
+      pix[i] = -1;
+      yx[i] = 0;
+    }
+  }
+
+  f32x4 wreg[WL], xreg[XL];
+  auto gload = [&](int chunk) {
+    const int k = chunk * BK + lq * 4;
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3;
+      const int n = n0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < BN && n < a.N) v = *reinterpret_cast<const f32x4*>(a.Wt + (long)n * a.Kp + k);
+      wreg[i] = v;
+    }
+    if (vec) {
+      int tap = 0, ci = k;
+      if (a.taps != 1) { tap = k / a.Cin; ci = k - tap * a.Cin; }
+      const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+      const bool kok = k < a.K;
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kok && pix[i] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+          v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix[i] + dy * a.W + dx) * a.ldx + ci);
+        xreg[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XL; ++i) xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k + j;
+        int tap = 0, ci = kk;
+        if (a.taps != 1) { tap = kk / a.Cin; ci = kk - tap * a.Cin; }
+        const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+        const bool kok = kk < a.K;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+          const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
+          if (kok && pix[i] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+            xreg[i][j] = a.X[(long)(pix[i] + dy * a.W + dx) * a.ldx + ci];
+        }
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* Ws = smem + buf * (BN + BM) * LS;
+    float* Xs = Ws + BN * LS;
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3;
+      if (r < BN) *reinterpret_cast<f32x4*>(Ws + r * LS + lq * 4) = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i)
+      *reinterpret_cast<f32x4*>(Xs + (lr + 32 * i) * LS + lq * 4) = xreg[i];
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (c_begin < c_end) {
+    gload(c_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) gload(c + 1);
+    const float* Ws = smem + buf * (BN + BM) * LS;
+    mfma_tile_step<TN, TM>(Ws, Ws + BN * LS, wn * 16 * TN, wm * 16 * TM, lane, acc);
+    if (c + 1 < c_end) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int nq = (lane >> 4) * 4, mi = lane & 15;
+  const bool ovec = ((a.ldo | a.N) & 3) == 0;
+  f32x4 cdl[TN], cdb[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) { cdl[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cdb[t] = cdl[t]; }
+  float* outp = a.out + (long)z * a.slab_stride;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * 16 * TN + tn * 16 + nq;
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {1.f, 1.f, 1.f, 1.f};
+    if (a.epi != EPI_RAW) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) {
+          if (a.epi == EPI_AN_RELU) e0[r] = a.e0[n + r];
+          e1[r] = a.e1[n + r];
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * 16 * TM + tm * 16 + mi;
+      if (m >= a.M || n >= a.N) continue;
+      f32x4 v = acc[tn][tm];
+      if (a.epi == EPI_AN_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf((v[r] + e0[r]) * e1[r], 0.f);
+      } else if (a.epi == EPI_DGRAD) {
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        const float* hp = a.hprev + (long)m * a.ldh + n;
+        if (n + 3 < a.N && ((a.ldh & 3) == 0)) h = *reinterpret_cast<const f32x4*>(hp);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < a.N) h[r] = hp[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = v[r];
+          cdl[tn][r] += g * h[r];
+          v[r] = h[r] > 0.f ? g * e1[r] : 0.f;
+          cdb[tn][r] += v[r];
+        }
+      }
+      float* op = outp + (long)m * a.ldo + n;
+      if (ovec && n + 3 < a.N) *reinterpret_cast<f32x4*>(op) = v;
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < a.N) op[r] = v[r];
+    }
+  }
+  if (a.epi == EPI_DGRAD) {
+    // column partial sums: over the 16 pixel-lanes, then over the WM waves through LDS
+    __syncthreads();
+    float* red = smem;  // [WM][2][BN]
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0 = cdl[tn][r], s1 = cdb[tn][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s0 += __shfl_xor(s0, off, 64);
+          s1 += __shfl_xor(s1, off, 64);
+        }
+        if (mi == 0) {
+          const int nl = wn * 16 * TN + tn * 16 + nq + r;
+          red[(wm * 2 + 0) * BN + nl] = s0;
+          red[(wm * 2 + 1) * BN + nl] = s1;
+        }
+      }
+    __syncthreads();
+    const int mb = bid / nNB;
+    for (int t = tid; t < 2 * BN; t += 256) {
+      const int which = t / BN, nl = t % BN;
+      if (n0 + nl < a.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + nl];
+        a.colsum[((long)mb * 2 + which) * a.N + n0 + nl] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad kernel: out[slab][i][j] = sum_{m in slab} P[m][i] * Qim2col[m][j],  j = tap*Cq + cq
+// ------------------------------------------------------------------------------------------
+
+template <int TN, int TM, int WN, int WM>
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+  constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
+  constexpr int PL = (BI * 8 + 255) / 256, QL = (BJ * 8 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid % WN, wm = wid / WN;
+  const int nIB = (a.NI + BI - 1) / BI, nJB = (a.J + BJ - 1) / BJ;
+  const int bid = xcd_remap(blockIdx.x, nIB * nJB);
+  const int i0 = (bid % nIB) * BI, j0 = (bid / nIB) * BJ;
+  const int HW = a.H * a.W;
+  const int S = gridDim.y, z = blockIdx.y;
+  const int nchunks = (a.M + BK - 1) / BK;
+  const int c_begin = (int)((long)nchunks * z / S), c_end = (int)((long)nchunks * (z + 1) / S);
+  const bool pvec = ((a.NI | a.ldp) & 3) == 0, qvec = ((a.Cq | a.ldq) & 3) == 0;
+
+  // thread -> (pixel within chunk, channel group of 4): channel groups fastest => coalesced rows
+  constexpr int PG = BI / 4, QG = BJ / 4;
+  f32x4 preg[PL], qreg[QL];
+  auto gload = [&](int chunk) {
+    const int mb = chunk * BK;
+#pragma unroll
+    for (int t = 0; t < PL; ++t) {
+      const int idx = tid + 256 * t;
+      const int pl = idx / PG, g = idx % PG;
+      const int m = mb + pl, i = i0 + g * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < BI * 8 && m < a.M && i < a.NI) {
+        const float* p = a.P + (long)m * a.ldp + i;
+        if (pvec) v = *reinterpret_cast<const f32x4*>(p);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (i + r < a.NI) v[r] = p[r];
+      }
+      preg[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < QL; ++t) {
+      const int idx = tid + 256 * t;
+      const int pl = idx / QG, g = idx % QG;
+      const int m = mb + pl, j = j0 + g * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < BJ * 8 && m < a.M && j < a.J) {
+        const int rem = m % HW, y = rem / a.W, x = rem % a.W;
+        if (qvec) {
+          int tap = 0, cq = j;
+          if (a.taps != 1) { tap = j / a.Cq; cq = j - tap * a.Cq; }
+          const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+          if ((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W)
+            v = *reinterpret_cast<const f32x4*>(a.Q + (long)(m + dy * a.W + dx) * a.ldq + cq);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int jj = j + r;
+            if (jj >= a.J) continue;
+            int tap = 0, cq = jj;
+            if (a.taps != 1) { tap = jj / a.Cq; cq = jj - tap * a.Cq; }
+            const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+            if ((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W)
+              v[r] = a.Q[(long)(m + dy * a.W + dx) * a.ldq + cq];
+          }
+        }
+      }
+      qreg[t] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* Ps = smem + buf * (BI + BJ) * LS;
+    float* Qs = Ps + BI * LS;
+#pragma unroll
+    for (int t = 0; t < PL; ++t) {
+      const int idx = tid + 256 * t;
+      const int pl = idx / PG, g = idx % PG;
+      if (idx < BI * 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ps[(g * 4 + r) * LS + pl] = preg[t][r];
+    }
+#pragma unroll
+    for (int t = 0; t < QL; ++t) {
+      const int idx = tid + 256 * t;
+      const int pl = idx / QG, g = idx % QG;
+      if (idx < BJ * 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Qs[(g * 4 + r) * LS + pl] = qreg[t][r];
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c_begin < c_end) {
+    gload(c_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) gload(c + 1);
+    const float* Ps = smem + buf * (BI + BJ) * LS;
+    mfma_tile_step<TN, TM>(Ps, Ps + BI * LS, wn * 16 * TN, wm * 16 * TM, lane, acc);
+    if (c + 1 < c_end) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int iq = (lane >> 4) * 4, jl = lane & 15;
+  float* outp = a.out + (long)z * a.slab_stride;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int i = i0 + wn * 16 * TN + tn * 16 + iq, j = j0 + wm * 16 * TM + tm * 16 + jl;
+      if (j >= a.J) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (i + r < a.NI) outp[(long)(i + r) * a.J + j] = acc[tn][tm][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight repack:  W[co][ci][taps]  ->  fwd  Wt[co][tap*Cin + ci]      (zero padded to Kp)
+//                                 ->  dgrad Wd[ci][tap'*Cout + co] = W[co][ci][taps-1-tap']
+// ------------------------------------------------------------------------------------------
+__global__ void repack_kernel(const float* __restrict__ W, int Cout, int Cin, int taps, float* __restrict__ Wt,
+                              int Kp, float* __restrict__ Wd, int Kpd) {
+  const long total_f = (long)Cout * Kp, total_d = Wd ? (long)Cin * Kpd : 0;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d;
+       t += (long)gridDim.x * blockDim.x) {
+    if (t < total_f) {
+      const int co = t / Kp, k = t % Kp;
+      float v = 0.f;
+      if (k < taps * Cin) {
+        const int tap = k / Cin, ci = k % Cin;
+        v = W[((long)co * Cin + ci) * taps + tap];
+      }
+      Wt[t] = v;
+    } else {
+      const long u = t - total_f;
+      const int ci = u / Kpd, k = u % Kpd;
+      float v = 0.f;
+      if (k < taps * Cout) {
+        const int tap = k / Cout, co = k % Cout;
+        v = W[((long)co * Cin + ci) * taps + (taps - 1 - tap)];
+      }
+      Wd[u] = v;
+    }
+  }
+}
+
+__global__ void repack_batch_kernel(const nfk_repack_desc* __restrict__ descs) {
+  const nfk_repack_desc d = descs[blockIdx.y];
+  const int Kp = (d.taps * d.Cin + BK - 1) / BK * BK, Kpd = (d.taps * d.Cout + BK - 1) / BK * BK;
+  const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d;
+       t += (long)gridDim.x * blockDim.x) {
+    if (t < total_f) {
+      const int co = t / Kp, k = t % Kp;
+      float v = 0.f;
+      if (k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];
+      d.wt[t] = v;
+    } else {
+      const long u = t - total_f;
+      const int ci = u / Kpd, k = u % Kpd;
+      float v = 0.f;
+      if (k < d.taps * d.Cout) v = d.w[((long)(k % d.Cout) * d.Cin + ci) * d.taps + (d.taps - 1 - k / d.Cout)];
+      d.wd[u] = v;
+    }
+  }
+}
+
+// wgrad finalize: gradW[co][ci][tap] += sum_slabs out[s][co][tap*Cin + ci]   (fixed order)
+__global__ void wgrad_finalize_kernel(const float* __restrict__ slabs, int S, long slab_stride, int Cout,
+                                      int Cin, int taps, float* __restrict__ gradW) {
+  const long total = (long)Cout * Cin * taps;
+  const int J = Cin * taps;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int tap = t % taps;
+    const long r = t / taps;
+    const int ci = r % Cin, co = r / Cin;
+    const long src = (long)co * J + tap * Cin + ci;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += slabs[i * slab_stride + src];
+    gradW[t] += s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+template <int TN, int TM, int WN, int WM>
+static int launch_conv(const ConvGemmArgs& a, int S, hipStream_t st) {
+  constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
+  constexpr size_t lds = 2 * (BN + BM) * LS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TN, TM, WN, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(a.N, BN) * ceil_div(a.M, BM), S);
+  hipLaunchKernelGGL((conv_gemm_kernel<TN, TM, WN, WM>), grid, dim3(256), lds, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+template <int TN, int TM, int WN, int WM>
+static int launch_wgrad(const WgradArgs& a, int S, hipStream_t st) {
+  constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
+  constexpr size_t lds = 2 * (BI + BJ) * LS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<TN, TM, WN, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(a.NI, BI) * ceil_div(a.J, BJ), S);
+  hipLaunchKernelGGL((wgrad_kernel<TN, TM, WN, WM>), grid, dim3(256), lds, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int padded_k(int K) { return ceil_div(K, BK) * BK; }
+
+// How many split-K slabs conv_gemm() will write for this problem (RAW epilogue only).
+int conv_splitk(int M, int N, int K, int epi) {
+  if (epi != EPI_RAW || N > 96) return 1;
+  const int nMB = ceil_div(M, 128), nk = ceil_div(K, BK);
+  int S = ceil_div(512, nMB);
+  if (S > nk / 4) S = nk / 4;
+  if (S < 1) S = 1;
+  if (S > 32) S = 32;
+  return S;
+}
+
+int conv_mblocks(int M, int N) {
+  if (N > 96) {
+    const bool big = (long)ceil_div(N, 128) * ceil_div(M, 128) >= 256;
+    return ceil_div(M, big ? 128 : 64);
+  }
+  return ceil_div(M, 128);
+}
+
+int conv_gemm(ConvGemmArgs a, hipStream_t st) {
+  if (a.taps != 1 && a.taps != 9) return NFK_ERR_ARG;
+  a.K = a.taps * a.Cin;
+  a.M = a.B * a.H * a.W;
+  a.nkchunks = ceil_div(a.K, BK);
+  if (a.Kp < a.nkchunks * BK) return NFK_ERR_ARG;
+  if (a.M <= 0 || a.N <= 0) return NFK_OK;
+  const int S = conv_splitk(a.M, a.N, a.K, a.epi);
+  if (a.N > 96) {
+    const bool big = (long)ceil_div(a.N, 128) * ceil_div(a.M, 128) >= 256;
+    return big ? launch_conv<4, 4, 2, 2>(a, S, st) : launch_conv<2, 2, 2, 2>(a, S, st);
+  }
+  switch (ceil_div(a.N, 16)) {
+    case 1: return launch_conv<1, 2, 1, 4>(a, S, st);
+    case 2: return launch_conv<2, 2, 1, 4>(a, S, st);
+    case 3: return launch_conv<3, 2, 1, 4>(a, S, st);
+    case 4: return launch_conv<4, 2, 1, 4>(a, S, st);
+    default: return launch_conv<6, 2, 1, 4>(a, S, st);
+  }
+}
+
+int wgrad_splits(int M, int NI, int J) {
+  const int tiles = (NI > 96 ? ceil_div(NI, 128) : 1) * ceil_div(J, 128);
+  const int nchunks = ceil_div(M, BK);
+  int S = ceil_div(768, tiles);
+  if (S > nchunks / 2) S = nchunks / 2;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  return S;
+}
+
+int wgrad_gemm(WgradArgs a, int S, hipStream_t st) {
+  a.M = a.B * a.H * a.W;
+  a.J = a.taps * a.Cq;
+  if (a.M <= 0 || a.NI <= 0 || a.J <= 0) return NFK_OK;
+  if (a.NI > 96) return launch_wgrad<4, 4, 2, 2>(a, S, st);
+  switch (ceil_div(a.NI, 16)) {
+    case 1: return launch_wgrad<1, 2, 1, 4>(a, S, st);
+    case 2: return launch_wgrad<2, 2, 1, 4>(a, S, st);
+    case 3: return launch_wgrad<3, 2, 1, 4>(a, S, st);
+    case 4: return launch_wgrad<4, 2, 1, 4>(a, S, st);
+    default: return launch_wgrad<6, 2, 1, 4>(a, S, st);
+  }
+}
+
+int repack_weights(const float* W, int Cout, int Cin, int taps, float* Wt, float* Wd, hipStream_t st) {
+  const int Kp = padded_k(taps * Cin), Kpd = padded_k(taps * Cout);
+  const long total = (long)Cout * Kp + (Wd ? (long)Cin * Kpd : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(repack_kernel, dim3(blocks), dim3(256), 0, st, W, Cout, Cin, taps, Wt, Kp, Wd, Kpd);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int repack_batch(const nfk_repack_desc* descs, int n, hipStream_t st) {
+  if (n <= 0) return NFK_OK;
+  hipLaunchKernelGGL(repack_batch_kernel, dim3(64, n), dim3(256), 0, st, descs);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int wgrad_finalize(const float* slabs, int S, long slab_stride, int Cout, int Cin, int taps, float* gradW,
+                   hipStream_t st) {
+  const long total = (long)Cout * Cin * taps;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, slabs, S, slab_stride, Cout, Cin,
+                     taps, gradW);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+}  // namespace nfk

@@ -1,0 +1,137 @@
+// Argument structs and launcher prototypes shared between the nfk translation units.
+#pragma once
+#include "nfk_device.h"
+#include "nfk_structs.h"
+
+namespace nfk {
+
+enum { EPI_RAW = 0, EPI_AN_RELU = 1, EPI_DGRAD = 2 };
+
+struct ConvGemmArgs {
+  const float* X;   // activations, NHWC rows: X[pixel*ldx + ci]
+  int ldx, B, H, W, Cin, taps, M, K;
+  const float* Wt;  // repacked weights [N][Kp], zero padded in k
+  int Kp, N;
+  float* out;       // out[slab*slab_stride + m*ldo + n]
+  int ldo;
+  long slab_stride;
+  int epi;
+  const float* e0;     // AN_RELU: bias[n]
+  const float* e1;     // AN_RELU / DGRAD: scale[n]
+  const float* hprev;  // DGRAD: post-ReLU activation of the layer being differentiated
+  int ldh;
+  float* colsum;       // DGRAD: [mblocks][2][N] partial column sums (dlogs, dbias)
+  int nkchunks;        // ceil(K/32)
+};
+
+struct WgradArgs {
+  const float* P; int ldp, NI;
+  const float* Q; int ldq, Cq, taps;
+  int B, H, W, M, J;   // J = taps*Cq
+  float* out; long slab_stride;  // out[slab][i*J + j]
+};
+
+struct ChanMixArgs {
+  const float* x; int ldx;
+  const float* Wm; const float* cv;
+  float* z; int ldz;
+  int M, C, trans;
+  // backward-only gather of g_z: first `Ch` channels = ga[m][c] + sum_s slab[s][m][c], rest from x
+  const float* ga; int lda; const float* gext; int ldge; const float* slab; int S; long slab_stride; int Ch;
+  // backward-only partial outer products: part[block][C*C + C]
+  const float* xin; int ldxin; float* part;
+};
+
+struct CouplingArgs {
+  const float* a3; int S; long slab_stride;   // conv3 raw partial sums [S][M][Cout]
+  const float* bias3; const float* es3;       // [Cout]
+  const float* z; int ldz;                    // [M][C] mixed input (z1 | z2)
+  float* zout; int ldo;                       // [M][C]
+  float* hsave;                               // [M][Cout] or null
+  const float* ld_in; const float* dld; float* ld_out;   // [B], scalar, [B]
+  int HW, C, Cout, additive, has_ld;
+};
+
+struct CouplingBwdArgs {
+  const float* gout; int ldg;      // grad wrt step output [M][C] (already includes hint grads)
+  const float* gext; int ldge;     // optional extra grad to add (external hint) or null
+  const float* gld;                // [B] grad wrt logdet
+  const float* z; int ldz;         // saved mixed z [M][C]
+  const float* h;                  // saved h [M][Cout]
+  const float* es3;
+  float* ga3;                      // [M][Cout] = g_h * es3  (operand of dgrad3 / wgrad3)
+  float* gz; int ldgz;             // [M][C]: second half written here (g_z2)
+  float* part;                     // [B][2][Cout]: (sum g_a3, 3 * sum g_h h)
+  int HW, C, Cout, additive;
+};
+
+struct SplitArgs {
+  const float* a; int S; long slab_stride;  // conv raw sums [S][M][C]
+  const float* bias; const float* es;       // [C]
+  const float* x; int ldx;                  // [M][C] input (z1 | z2)
+  float* z1out;                             // [M][C/2]
+  float* hsave;                             // [M][C] (mean,logs interleaved) or null
+  const float* ld_in; float* ld_out;
+  int HW, C, has_ld;
+  // inverse only
+  const float* eps; float temperature;      // eps [M][C/2] or null
+};
+
+struct SplitBwdArgs {
+  const float* gld;              // [B]
+  const float* x; int ldx;       // saved input [M][C]
+  const float* h;                // saved (mean,logs) [M][C]
+  const float* es;
+  float* ga;                     // [M][C] grad wrt raw conv sums
+  float* gx; int ldgx;           // [M][C]: second half written (g_z2)
+  float* part;                   // [B][2][C]
+  int HW, C;
+};
+
+struct PriorArgs {
+  const float* z; int ldz;         // [B][HW][C] NHWC (1-D: HW = 1)
+  const float* ph; long ph_bstride; // prior tensor [b?][2C][HW] (NCHW order), batch stride (0 = shared)
+  const float* ld; float* objective; float* bpd;
+  int HW, C; float bpd_scale;      // bpd = -objective * bpd_scale
+};
+
+struct PriorBwdArgs {
+  const float* z; int ldz; const float* ph; long ph_bstride;
+  const float* gbpd;        // [B]
+  float* gz; int ldgz;      // [B][HW][C]
+  float* gld;               // [B]  = d loss / d logdet
+  float* gph;               // [B][2C][HW] or null
+  int HW, C; float bpd_scale;
+};
+
+int padded_k(int K);
+int conv_splitk(int M, int N, int K, int epi);
+int conv_mblocks(int M, int N);
+int conv_gemm(ConvGemmArgs a, hipStream_t st);
+int wgrad_splits(int M, int NI, int J);
+int wgrad_gemm(WgradArgs a, int S, hipStream_t st);
+int repack_weights(const float* W, int Cout, int Cin, int taps, float* Wt, float* Wd, hipStream_t st);
+int repack_batch(const nfk_repack_desc* descs, int n, hipStream_t st);
+int wgrad_finalize(const float* slabs, int S, long slab_stride, int Cout, int Cin, int taps, float* gradW,
+                   hipStream_t st);
+int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st);
+int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
+                    int any_dense, hipStream_t st);
+int launch_chanmix(const ChanMixArgs& a, hipStream_t st);
+int chanmix_blocks(int M);
+int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st);
+int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st);
+int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
+int launch_squeeze_nchw(float* x, const float* noise, float* out, int B, int C, int H, int W, hipStream_t st);
+int launch_squeeze_nhwc(const float* x, int ldx, float* out, int B, int C, int H, int W, hipStream_t st);
+int launch_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st);
+int launch_split_fwd(const SplitArgs& a, int B, hipStream_t st);
+int launch_split_inv(const SplitArgs& a, int B, hipStream_t st);
+int launch_split_bwd(const SplitBwdArgs& a, int B, hipStream_t st);
+int launch_add_slabs(const float* g, int ldg, const float* gext, int ldge, const float* slab, int S,
+                     long slab_stride, float* out, int ldo, long M, int Ch, hipStream_t st);
+int launch_prior_fwd(const PriorArgs& a, int B, hipStream_t st);
+int launch_prior_bwd(const PriorBwdArgs& a, int B, hipStream_t st);
+int launch_small_grads(const SmallGradArgs& a, hipStream_t st);
+
+}  // namespace nfk

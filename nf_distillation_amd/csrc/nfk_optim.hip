@@ -1,0 +1,82 @@
+// Student optimiser on flat fp32 buffers: global grad-norm clip + Adam in two launches.
+// Restates torch.nn.utils.clip_grad_norm_(30) (PL gradient_clip_val, train.py:46) and
+// torch.optim.Adam (pl_module.py:350-354) for one contiguous parameter arena.
+#include "nfk_internal.h"
+
+namespace nfk {
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256) sumsq_stage1(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+  __shared__ float sh[32];
+  float s = 0.f;
+  const size_t n4 = n / 4;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = g4[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) sumsq_stage2(const float* __restrict__ partial, int nblocks, float* __restrict__ out) {
+  __shared__ float sh[32];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] += s;
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, const float* __restrict__ sumsq,
+                                                   float clip, float gscale, float step_size, float beta1,
+                                                   float beta2, float inv_sqrt_bc2, float eps, float wd) {
+  float coef = gscale;
+  if (sumsq && clip > 0.f) {
+    const float norm = sqrtf(sumsq[0]) * gscale;
+    const float c = clip / (norm + 1e-6f);
+    coef *= c < 1.f ? c : 1.f;
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * coef;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}
+
+}  // namespace nfk
+
+using namespace nfk;
+extern "C" {
+int nfk_sumsq(const float* g, size_t n, float* partial, float* sumsq, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((reinterpret_cast<uintptr_t>(g) & 15) != 0) return NFK_ERR_ARG;
+  size_t want = (n / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > SUMSQ_BLOCKS ? SUMSQ_BLOCKS : want));
+  hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, st, g, n, partial);
+  NFK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, partial, blocks, sumsq);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* sumsq, float clip,
+                  float gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (step < 1) return NFK_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  size_t want = (n + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, gscale,
+                     (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, weight_decay);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+}

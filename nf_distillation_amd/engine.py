@@ -1,0 +1,599 @@
+"""FlowEngine: runs a list of flow layers (SqueezeLayer / FlowStep / Split2d) through libnfk.
+
+One engine per ``FlowNet``.  It owns, per (batch, input shape, device):
+  * the ctypes descriptors of every layer (raw parameter pointers, shapes),
+  * the "prep" arena: per-step fused ActNorm x invconv matrices, log-det constants, exp(logs)
+    vectors and the repacked conv weights -- produced by TWO launches for the whole model
+    (``nfk_prep`` + ``nfk_repack_batch``) and cached while parameters are frozen (teacher),
+  * nothing else: activations are allocated per call from torch's caching allocator.
+
+Autograd: the whole encode is ONE ``torch.autograd.Function`` node.  Its backward walks the
+layers in reverse through ``nfk_step2d_bwd`` / ``nfk_split2d_bwd`` and accumulates parameter
+gradients straight into ``param.grad`` (pre-allocated, e.g. views of one flat buffer --
+see training.FlatParams), so no per-parameter autograd bookkeeping runs on the hot path.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+from .capi import PrepDesc, PrepGrad, RepackDesc, Split2d as CSplit2d, Step2d, Step2dGrads, check, ptr
+
+
+def _a4(n):
+    return (n + 3) & ~3
+
+
+class _Rec:
+    __slots__ = ("kind", "idx", "mod", "C", "H", "W", "hid", "Cout", "additive", "cs", "prep_i", "views",
+                 "params", "tab")
+
+
+def _nhwc(t):
+    """[B,C,H,W] logical tensor -> dense [B,H,W,C] tensor (no copy if already channels-last)."""
+    p = t.permute(0, 2, 3, 1)
+    return p if p.is_contiguous() else p.contiguous()
+
+
+def _check_param(p, name):
+    if p.dtype != torch.float32 or not p.is_contiguous():
+        raise TypeError(f"{name}: nfk kernels need contiguous fp32 parameters")
+    capi.require_cuda(p, name)
+
+
+class FlowEngine:
+    def __init__(self, layers):
+        from . import modules as M
+        self.M = M
+        self.layers = layers
+        self.state = None
+        self.key = None
+        self.is_1d = any(isinstance(l, M.FlowStep) and l.is_1d for l in layers)
+        self._params = None
+
+    # ------------------------------------------------------------------ parameters
+    def params(self):
+        if self._params is None:
+            ps = []
+            for l in self.layers:
+                ps.extend(p for p in l.parameters())
+            self._params = ps
+        return self._params
+
+    def _signature(self):
+        sig = []
+        for l in self.layers:
+            for t in list(l.parameters()) + list(l.buffers()):
+                sig.append(t.data_ptr())
+        return tuple(sig)
+
+    def _version(self):
+        v = 0
+        for l in self.layers:
+            for t in list(l.parameters()) + list(l.buffers()):
+                v += t._version
+        return v
+
+    def mark_dirty(self):
+        if self.state is not None:
+            self.state["version"] = None
+
+    # ------------------------------------------------------------------ build
+    def _build(self, B, in_shape, device):
+        M = self.M
+        lib = capi.lib()
+        recs, prep_descs, repack_descs = [], [], []
+        if self.is_1d:
+            Cc, H, W = in_shape[0], 1, 1
+        else:
+            Cc, H, W = in_shape
+        prep_floats = 0
+        pack_floats = 0
+        plan = []  # (rec, offsets)
+        for i, layer in enumerate(self.layers):
+            r = _Rec()
+            r.idx, r.mod, r.prep_i, r.cs, r.tab = i, layer, -1, None, None
+            if isinstance(layer, M.SqueezeLayer):
+                r.kind, r.C, r.H, r.W = "squeeze", Cc, H, W  # INPUT dims
+                Cc, H, W = Cc * 4, H // 2, W // 2
+            elif isinstance(layer, M.FlowStep):
+                if layer.in_channels != Cc:
+                    raise ValueError(f"layer {i}: expected {layer.in_channels} channels, got {Cc}")
+                r.kind = "tab" if layer.is_1d else "step"
+                r.C, r.H, r.W, r.hid = Cc, H, W, layer.hidden_channels
+                r.additive = 1 if layer.flow_coupling == "additive" else 0
+                r.Cout = (Cc - Cc // 2) * (1 if r.additive else 2)
+                off = {}
+                o = prep_floats
+                for name, n in (("Wf", Cc * Cc), ("cf", Cc), ("Wi", Cc * Cc), ("ci", Cc), ("dld", 4),
+                                ("es1", 0 if layer.is_1d else r.hid), ("es2", 0 if layer.is_1d else r.hid),
+                                ("es3", 0 if layer.is_1d else r.Cout), ("scratch", 5 * Cc * Cc)):
+                    off[name] = o
+                    o += _a4(n)
+                prep_floats = o
+                if not layer.is_1d:
+                    Ch, hid = Cc // 2, r.hid
+                    o = pack_floats
+                    for name, n in (("wt1", hid * lib.nfk_padded_k(9 * Ch)), ("wd1", Ch * lib.nfk_padded_k(9 * hid)),
+                                    ("wt2", hid * lib.nfk_padded_k(hid)), ("wd2", hid * lib.nfk_padded_k(hid)),
+                                    ("wt3", r.Cout * lib.nfk_padded_k(9 * hid)),
+                                    ("wd3", hid * lib.nfk_padded_k(9 * r.Cout))):
+                        off[name] = o
+                        o += _a4(n)
+                    pack_floats = o
+                plan.append((r, off))
+            elif isinstance(layer, M.Split2d):
+                r.kind, r.C, r.H, r.W = "split", Cc, H, W
+                off = {"es3": prep_floats}
+                prep_floats += _a4(Cc)
+                Ch = Cc // 2
+                off["wt"] = pack_floats
+                pack_floats += _a4(Cc * lib.nfk_padded_k(9 * Ch))
+                off["wd"] = pack_floats
+                pack_floats += _a4(Ch * lib.nfk_padded_k(9 * Cc))
+                plan.append((r, off))
+                Cc = Cc // 2
+            else:
+                raise TypeError(f"unsupported layer type {type(layer).__name__}")
+            recs.append(r)
+
+        prep_buf = torch.zeros(max(prep_floats, 4), dtype=torch.float32, device=device)
+        pack_buf = torch.zeros(max(pack_floats, 4), dtype=torch.float32, device=device)
+        pb, kb = prep_buf.data_ptr(), pack_buf.data_ptr()
+        keep = []  # tensors that must stay alive (perm indices, zero vectors)
+        any_dense = 0
+        for r, off in plan:
+            layer = r.mod
+            d = PrepDesc()
+            if r.kind in ("step", "tab"):
+                an = layer.actnorm
+                _check_param(an.bias, "actnorm.bias")
+                d.C, d.pixels, d.is_1d = r.C, r.H * r.W, 1 if layer.is_1d else 0
+                d.an_bias, d.an_logs = ptr(an.bias), ptr(an.logs)
+                if layer.flow_permutation_type == "invconv":
+                    ic = layer.invconv
+                    if ic.LU_decomposed:
+                        d.perm_kind = 0
+                        for nm in ("lower", "upper", "log_s", "p", "sign_s"):
+                            t = getattr(ic, nm)
+                            _check_param(t, "invconv." + nm)
+                            setattr(d, nm, ptr(t))
+                    else:
+                        d.perm_kind = 1
+                        any_dense = 1
+                        _check_param(ic.weight, "invconv.weight")
+                        d.weight = ptr(ic.weight)
+                else:
+                    perm = layer.shuffle if layer.flow_permutation_type == "shuffle" else layer.reverse
+                    idx = perm.indices.to(device=device, dtype=torch.int32).contiguous()
+                    keep.append(idx)
+                    d.perm_kind = 2
+                    d.perm_idx = ptr(idx)
+                for nm in ("Wf", "cf", "Wi", "ci", "dld", "scratch"):
+                    setattr(d, nm, pb + 4 * off[nm])
+                if r.kind == "step":
+                    blk = layer.block
+                    d.n1 = d.n2 = r.hid
+                    d.n3 = r.Cout
+                    d.l1, d.l2, d.l3 = ptr(blk[0].actnorm.logs), ptr(blk[2].actnorm.logs), ptr(blk[4].logs)
+                    for nm in ("es1", "es2", "es3"):
+                        setattr(d, nm, pb + 4 * off[nm])
+                    cs = Step2d()
+                    cs.B, cs.H, cs.W, cs.C, cs.hidden, cs.Cout, cs.additive = B, r.H, r.W, r.C, r.hid, r.Cout, r.additive
+                    cs.b1, cs.b2, cs.bias3 = ptr(blk[0].actnorm.bias), ptr(blk[2].actnorm.bias), ptr(blk[4].conv.bias)
+                    for nm in ("Wf", "cf", "Wi", "ci", "dld", "es1", "es2", "es3"):
+                        setattr(cs, nm, pb + 4 * off[nm])
+                    for nm in ("wt1", "wt2", "wt3", "wd1", "wd2", "wd3"):
+                        setattr(cs, nm, kb + 4 * off[nm])
+                    r.cs = cs
+                    Ch = r.C // 2
+                    for w, co, ci, taps, a, b in ((blk[0].conv.weight, r.hid, Ch, 9, "wt1", "wd1"),
+                                                  (blk[2].conv.weight, r.hid, r.hid, 1, "wt2", "wd2"),
+                                                  (blk[4].conv.weight, r.Cout, r.hid, 9, "wt3", "wd3")):
+                        _check_param(w, "conv.weight")
+                        if tuple(w.shape) != (co, ci, 3 if taps == 9 else 1, 3 if taps == 9 else 1):
+                            raise ValueError(f"layer {r.idx}: unexpected conv weight shape {tuple(w.shape)}")
+                        rd = RepackDesc()
+                        rd.w, rd.wt, rd.wd = ptr(w), kb + 4 * off[a], kb + 4 * off[b]
+                        rd.Cout, rd.Cin, rd.taps = co, ci, taps
+                        repack_descs.append(rd)
+                else:
+                    from .tabular import TabStep
+                    r.tab = TabStep(r, B, pb, off)
+            else:  # split
+                cz = layer.conv
+                d.C, d.pixels, d.n3, d.l3, d.es3 = 0, r.H * r.W, r.C, ptr(cz.logs), pb + 4 * off["es3"]
+                cs = CSplit2d()
+                cs.B, cs.H, cs.W, cs.C = B, r.H, r.W, r.C
+                cs.bias, cs.es = ptr(cz.conv.bias), pb + 4 * off["es3"]
+                cs.wt, cs.wd = kb + 4 * off["wt"], kb + 4 * off["wd"]
+                r.cs = cs
+                rd = RepackDesc()
+                rd.w, rd.wt, rd.wd = ptr(cz.conv.weight), cs.wt, cs.wd
+                rd.Cout, rd.Cin, rd.taps = r.C, r.C // 2, 9
+                repack_descs.append(rd)
+            r.prep_i = len(prep_descs)
+            prep_descs.append(d)
+
+        self.state = {
+            "B": B, "recs": recs, "prep_buf": prep_buf, "pack_buf": pack_buf, "keep": keep,
+            "prep_dev": capi.struct_array_to_device(prep_descs, device), "n_prep": len(prep_descs),
+            "prep_host": prep_descs,
+            "repack_dev": capi.struct_array_to_device(repack_descs, device), "n_repack": len(repack_descs),
+            "any_dense": any_dense, "version": None, "has_inverse": False, "sig": self._signature(),
+            "out_shape": (Cc, H, W), "grad_sig": None, "grad_dev": None,
+        }
+
+    def _ensure(self, x):
+        capi.require_cuda(x, "input")
+        if x.dtype != torch.float32:
+            raise TypeError("nfk kernels compute in fp32; got " + str(x.dtype))
+        B = x.shape[0]
+        in_shape = tuple(x.shape[1:])
+        key = (B, in_shape, x.device)
+        if self.state is None or self.key != key or self.state["sig"] != self._signature():
+            self._build(B, in_shape, x.device)
+            self.key = key
+        return self.state
+
+    def _refresh(self, st, want_inverse):
+        """Run prep (+ repack) if parameters may have changed since the cached products were made."""
+        trainable = any(p.requires_grad for p in self.params())
+        ver = self._version()
+        fresh = (not trainable) and st["version"] == ver and (st["has_inverse"] or not want_inverse)
+        if fresh:
+            return
+        lib, s = capi.lib(), capi.stream()
+        check(lib.nfk_prep(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, s), "nfk_prep")
+        check(lib.nfk_repack_batch(ptr(st["repack_dev"]), st["n_repack"], s), "nfk_repack_batch")
+        st["version"], st["has_inverse"] = ver, bool(want_inverse)
+
+    # ------------------------------------------------------------------ public entry points
+    def encode(self, x, y_onehot, logdet, noise=None):
+        if y_onehot is not None and not self.is_1d:
+            # the reference concatenates a [B,classes] tensor to a 4-D one here (models/flows.py:153)
+            raise RuntimeError("Tensors must have same number of dimensions: got 4 and 2")
+        B = x.shape[0]
+        if not torch.is_tensor(logdet):
+            logdet = torch.full((B,), float(logdet), device=x.device, dtype=torch.float32)
+        res = _EncodeFn.apply(self, x, logdet, noise, y_onehot, *self.params())
+        return list(res[:-1]), res[-1]
+
+    @torch.no_grad()
+    def decode(self, z, y_onehot, temperature, eps=None):
+        """Reverse pass (no autograd).  `eps`: {layer index: N(0,1) tensor [B,C/2,H,W]} for Split2d."""
+        st = self._ensure_for_decode(z)
+        self._refresh(st, True)
+        lib, s = capi.lib(), capi.stream()
+        B = z.shape[0]
+        outs = []
+        if self.is_1d:
+            cur = z.contiguous()
+            for r in reversed(st["recs"]):
+                cur = r.tab.inverse(cur, y_onehot)
+                outs.append(cur)
+            return outs
+        cur = _nhwc(z)
+        scratch = _Scratch(st, z.device)
+        recs = st["recs"]
+        for n, r in enumerate(reversed(recs)):
+            last = n == len(recs) - 1
+            if r.kind == "step":
+                M_ = B * r.H * r.W
+                out = torch.empty((B, r.H, r.W, r.C), device=z.device, dtype=torch.float32)
+                zb, h1, h2, ws = scratch.get(M_ * r.C, M_ * r.hid, M_ * r.hid, lib.nfk_step2d_fwd_ws_floats(C.byref(r.cs)))
+                check(lib.nfk_step2d_inv(C.byref(r.cs), ptr(cur), r.C, None, ptr(zb), ptr(h1), ptr(h2), ptr(ws),
+                                         ptr(out), None, s), "nfk_step2d_inv")
+                cur = out
+                outs.append(out.permute(0, 3, 1, 2))
+            elif r.kind == "split":
+                out = torch.empty((B, r.H, r.W, r.C), device=z.device, dtype=torch.float32)
+                e = None
+                T = 0.0 if temperature is None else float(temperature)
+                if eps is not None and r.idx in eps:
+                    e = _nhwc(eps[r.idx].to(torch.float32))
+                elif T != 0.0:
+                    e = torch.randn((B, r.H, r.W, r.C // 2), device=z.device, dtype=torch.float32)
+                (ws,) = scratch.get(lib.nfk_split2d_fwd_ws_floats(C.byref(r.cs)))
+                check(lib.nfk_split2d_inv(C.byref(r.cs), ptr(cur), ptr(e), T, ptr(out), ptr(ws), s), "nfk_split2d_inv")
+                cur = out
+                outs.append(out.permute(0, 3, 1, 2))
+            else:  # unsqueeze: r holds the UNsqueezed dims
+                if last:
+                    out = torch.empty((B, r.C, r.H, r.W), device=z.device, dtype=torch.float32)
+                    check(lib.nfk_unsqueeze(ptr(cur), ptr(out), B, r.C, r.H, r.W, 1, s), "nfk_unsqueeze")
+                    outs.append(out)
+                else:
+                    out = torch.empty((B, r.H, r.W, r.C), device=z.device, dtype=torch.float32)
+                    check(lib.nfk_unsqueeze(ptr(cur), ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze")
+                    outs.append(out.permute(0, 3, 1, 2))
+                cur = out
+        return outs
+
+    def decode_single(self, z, y_onehot, temperature, eps=None):
+        return self.decode(z, y_onehot, temperature, eps)[-1]
+
+    def _ensure_for_decode(self, z):
+        """The engine is keyed on the INPUT shape of the first layer; derive it from the latent."""
+        M = self.M
+        if self.is_1d:
+            return self._ensure(z)
+        Cc, H, W = z.shape[1:]
+        for l in reversed(self.layers):
+            if isinstance(l, M.SqueezeLayer):
+                Cc, H, W = Cc // 4, H * 2, W * 2
+            elif isinstance(l, M.Split2d):
+                Cc = Cc * 2
+        capi.require_cuda(z, "z")
+        key = (z.shape[0], (Cc, H, W), z.device)
+        if self.state is None or self.key != key or self.state["sig"] != self._signature():
+            self._build(z.shape[0], (Cc, H, W), z.device)
+            self.key = key
+        return self.state
+
+
+class _Scratch:
+    """Re-usable scratch tensors for passes that keep nothing (teacher forward, reverse pass)."""
+
+    def __init__(self, st, device):
+        self.device = device
+        self.bufs = []
+
+    def get(self, *sizes):
+        out = []
+        for i, n in enumerate(sizes):
+            n = max(int(n), 4)
+            if i >= len(self.bufs):
+                self.bufs.append(torch.empty(n, device=self.device, dtype=torch.float32))
+            elif self.bufs[i].numel() < n:
+                self.bufs[i] = torch.empty(n, device=self.device, dtype=torch.float32)
+            out.append(self.bufs[i])
+        return out
+
+
+class _EncodeFn(torch.autograd.Function):
+    """All layers of a FlowNet, forward (models/kd_flows.py:42-53) and backward, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, eng, x, logdet, noise, y_onehot, *params):
+        st = eng._ensure(x)
+        eng._refresh(st, False)
+        lib, s = capi.lib(), capi.stream()
+        B, dev = x.shape[0], x.device
+        need = any(ctx.needs_input_grad)
+        ctx.set_materialize_grads(False)
+        ctx.eng, ctx.need, ctx.B = eng, need, B
+        ld = logdet.to(torch.float32).contiguous()
+        outs, saved = [], []
+        if eng.is_1d:
+            cur = x.contiguous()
+            for r in st["recs"]:
+                cur, ld, sv = r.tab.forward(cur, ld, y_onehot, need)
+                outs.append(cur)
+                saved.append(sv)
+            ctx.saved, ctx.x_in = saved, x
+            ctx.y_onehot = y_onehot
+            return tuple(outs) + (ld,)
+
+        scratch = _Scratch(st, dev)
+        cur, cur_ld = None, None  # NHWC tensor of the running activation
+        for r in st["recs"]:
+            if r.kind == "squeeze":
+                out = torch.empty((B, r.H // 2, r.W // 2, 4 * r.C), device=dev, dtype=torch.float32)
+                if cur is None:
+                    if x.is_contiguous():
+                        check(lib.nfk_squeeze(ptr(x), 0, ptr(noise), ptr(out), B, r.C, r.H, r.W, 1, s), "nfk_squeeze")
+                    else:
+                        if noise is not None:
+                            x.add_(noise)
+                        xs = _nhwc(x)
+                        check(lib.nfk_squeeze(ptr(xs), r.C, None, ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_squeeze")
+                else:
+                    check(lib.nfk_squeeze(ptr(cur), r.C, None, ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_squeeze")
+                saved.append(None)
+            elif r.kind == "step":
+                if cur is None:
+                    cur = _nhwc(x)
+                M_ = B * r.H * r.W
+                out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                ld_out = torch.empty_like(ld)
+                nws = lib.nfk_step2d_fwd_ws_floats(C.byref(r.cs))
+                if need:
+                    arena = torch.empty(_a4(M_ * r.C) + 2 * _a4(M_ * r.hid) + _a4(M_ * r.Cout), device=dev,
+                                        dtype=torch.float32)
+                    o1 = _a4(M_ * r.C)
+                    o2 = o1 + _a4(M_ * r.hid)
+                    o3 = o2 + _a4(M_ * r.hid)
+                    zb, h1, h2, hs = arena[:o1], arena[o1:o2], arena[o2:o3], arena[o3:]
+                    (ws,) = scratch.get(nws)
+                    saved.append((cur, zb, h1, h2, hs, arena))
+                else:
+                    zb, h1, h2, ws = scratch.get(M_ * r.C, M_ * r.hid, M_ * r.hid, nws)
+                    hs = None
+                    saved.append(None)
+                check(lib.nfk_step2d_fwd(C.byref(r.cs), ptr(cur), r.C, ptr(ld), ptr(zb), ptr(h1), ptr(h2), ptr(hs),
+                                         ptr(ws), ptr(out), ptr(ld_out), s), "nfk_step2d_fwd")
+                ld = ld_out
+            else:  # split
+                if cur is None:
+                    cur = _nhwc(x)
+                M_ = B * r.H * r.W
+                out = torch.empty((B, r.H, r.W, r.C // 2), device=dev, dtype=torch.float32)
+                ld_out = torch.empty_like(ld)
+                hs = torch.empty(M_ * r.C, device=dev, dtype=torch.float32) if need else None
+                (ws,) = scratch.get(lib.nfk_split2d_fwd_ws_floats(C.byref(r.cs)))
+                check(lib.nfk_split2d_fwd(C.byref(r.cs), ptr(cur), ptr(ld), ptr(out), ptr(hs), ptr(ws), ptr(ld_out), s),
+                      "nfk_split2d_fwd")
+                saved.append((cur, hs) if need else None)
+                ld = ld_out
+            cur = out
+            outs.append(out.permute(0, 3, 1, 2))
+        ctx.saved = saved
+        ctx.x_contig = x.is_contiguous()
+        return tuple(outs) + (ld,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        eng, B = ctx.eng, ctx.B
+        st = eng.state
+        lib, s = capi.lib(), capi.stream()
+        recs = st["recs"]
+        g_outs, g_ld = grads[:-1], grads[-1]
+        dev = st["prep_buf"].device
+        if g_ld is None:
+            g_ld = torch.zeros(B, device=dev, dtype=torch.float32)
+        g_ld = g_ld.to(torch.float32).contiguous()
+        n_in = 5 + len(eng.params())
+        if eng.is_1d:
+            g = None
+            for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):
+                if go is not None:
+                    g = go.contiguous() if g is None else g + go
+                g = r.tab.backward(sv, g, g_ld, ctx.y_onehot)
+            gx = g if ctx.needs_input_grad[1] else None
+            return (None, gx, g_ld if ctx.needs_input_grad[2] else None) + (None,) * (n_in - 3)
+
+        # make sure every parameter has a grad buffer the kernels can accumulate into
+        for p in eng.params():
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+        scratch = _Scratch(st, dev)
+        # per-step partial (gWf, gcf) arena for nfk_prep_bwd
+        part_off, total = {}, 0
+        for r in recs:
+            if r.kind == "step":
+                nb = lib.nfk_chanmix_blocks(B * r.H * r.W)
+                part_off[r.idx] = (total, nb)
+                total += _a4(nb * (r.C * r.C + r.C))
+        parts = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
+
+        g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
+        for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):
+            ext = _nhwc(go.to(torch.float32)) if go is not None else None
+            if g is None and ext is None:
+                continue  # nothing flows into this layer's output
+            if r.kind == "step":
+                x_in, zb, h1, h2, hs, _ = sv
+                blk = r.mod.block
+                gs = Step2dGrads()
+                gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
+                gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
+                gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
+                off, nb = part_off[r.idx]
+                gs.mix_part = parts.data_ptr() + 4 * off
+                gx = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                (ws,) = scratch.get(lib.nfk_step2d_bwd_ws_floats(C.byref(r.cs)))
+                g_main, g_ext = (g, ext) if g is not None else (ext, None)
+                check(lib.nfk_step2d_bwd(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
+                                         ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws), s), "nfk_step2d_bwd")
+                g = gx
+            elif r.kind == "split":
+                x_in, hs = sv
+                cz = r.mod.conv
+                gx = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                (ws,) = scratch.get(lib.nfk_split2d_bwd_ws_floats(C.byref(r.cs)))
+                g_main, g_ext = (g, ext) if g is not None else (ext, None)
+                check(lib.nfk_split2d_bwd(C.byref(r.cs), ptr(x_in), ptr(hs), ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx),
+                                          ptr(cz.conv.weight.grad), ptr(cz.conv.bias.grad), ptr(cz.logs.grad), ptr(ws), s),
+                      "nfk_split2d_bwd")
+                g = gx
+            else:  # squeeze: grad of the input = unsqueeze of the grad
+                tot = g if ext is None else (ext if g is None else g + ext)
+                first = r is recs[0]
+                if first and not ctx.needs_input_grad[1]:
+                    g = None
+                    continue
+                if first and ctx.x_contig:
+                    gx = torch.empty((B, r.C, r.H, r.W), device=dev, dtype=torch.float32)
+                    check(lib.nfk_unsqueeze(ptr(tot), ptr(gx), B, r.C, r.H, r.W, 1, s), "nfk_unsqueeze")
+                    g = gx
+                else:
+                    gx = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                    check(lib.nfk_unsqueeze(ptr(tot), ptr(gx), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze")
+                    g = gx if not first else gx.permute(0, 3, 1, 2)
+
+        # parameter-side chain for all steps in one launch
+        pg = []
+        for r in recs:
+            d = PrepGrad()
+            if r.kind == "step":
+                off, nb = part_off[r.idx]
+                d.part, d.nparts = parts.data_ptr() + 4 * off, nb
+                an = r.mod.actnorm
+                d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
+                if r.mod.flow_permutation_type == "invconv":
+                    ic = r.mod.invconv
+                    if ic.LU_decomposed:
+                        d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
+                    else:
+                        d.g_weight = ptr(ic.weight.grad)
+            if r.kind in ("step", "split"):
+                pg.append(d)
+        sig = tuple((d.part, d.g_an_bias, d.g_lower, d.g_weight) for d in pg)
+        if st["grad_sig"] != sig:
+            st["grad_dev"], st["grad_sig"] = capi.struct_array_to_device(pg, dev), sig
+        check(lib.nfk_prep_bwd(ptr(st["prep_dev"]), ptr(st["grad_dev"]), st["n_prep"], ptr(g_ld), B, st["any_dense"], s),
+              "nfk_prep_bwd")
+        ctx.keep = (parts,)
+        gx = g if ctx.needs_input_grad[1] else None
+        if gx is not None and gx.dim() == 4 and recs[0].kind != "squeeze":
+            gx = gx.permute(0, 3, 1, 2)
+        return (None, gx, g_ld if ctx.needs_input_grad[2] else None) + (None,) * (n_in - 3)
+
+
+class _PriorFn(torch.autograd.Function):
+    """objective = logdet + log N(z_top; prior) and bits/dim (models/kd_flows.py:136-150)."""
+
+    @staticmethod
+    def forward(ctx, z, prior, ld, scale):
+        lib, s = capi.lib(), capi.stream()
+        is_1d = z.dim() == 2
+        zz = z.contiguous() if is_1d else _nhwc(z)
+        B = zz.shape[0]
+        Cc = zz.shape[-1]
+        HW = 1 if is_1d else zz.shape[1] * zz.shape[2]
+        pr = prior.to(torch.float32)
+        bstride = 0 if (pr.shape[0] == 1 or pr.stride(0) == 0) else 2 * Cc * HW
+        pr = (pr[:1] if bstride == 0 else pr).contiguous()
+        obj = torch.empty(B, device=z.device, dtype=torch.float32)
+        bpd = torch.empty(B, device=z.device, dtype=torch.float32)
+        ld = ld.contiguous()
+        check(lib.nfk_prior_fwd(ptr(zz), Cc, ptr(pr), bstride, ptr(ld), ptr(obj), ptr(bpd), B, HW, Cc, scale, s),
+              "nfk_prior_fwd")
+        ctx.meta = (zz, pr, bstride, B, HW, Cc, scale, is_1d, prior.shape)
+        return bpd
+
+    @staticmethod
+    def backward(ctx, g_bpd):
+        zz, pr, bstride, B, HW, Cc, scale, is_1d, pshape = ctx.meta
+        lib, s = capi.lib(), capi.stream()
+        gz = torch.empty_like(zz)
+        gld = torch.empty(B, device=zz.device, dtype=torch.float32)
+        gp = None
+        if ctx.needs_input_grad[1]:
+            gp = torch.empty((B, 2 * Cc) + tuple(pshape[2:]), device=zz.device, dtype=torch.float32)
+        check(lib.nfk_prior_bwd(ptr(zz), Cc, ptr(pr), bstride, ptr(g_bpd.contiguous()), ptr(gz), Cc, ptr(gld), ptr(gp),
+                                B, HW, Cc, scale, s), "nfk_prior_bwd")
+        if gp is not None and pshape[0] == 1:
+            gp = gp.sum(0, keepdim=True)
+        return (gz if is_1d else gz.permute(0, 3, 1, 2)), gp, gld, None
+
+
+def prior_bpd(z_last, prior_t, logdet, scale):
+    return _PriorFn.apply(z_last, prior_t, logdet, float(scale))
+
+
+def run_single_layer(layer, input, y_onehot, logdet, reverse, temperature=None, eps=None):
+    """`layer(input, ...)` for a lone FlowStep / SqueezeLayer / Split2d, as the reference allows."""
+    eng = getattr(layer, "_solo_engine", None)
+    if eng is None:
+        eng = FlowEngine([layer])
+        object.__setattr__(layer, "_solo_engine", eng)
+    if not reverse:
+        ld_in = 0.0 if logdet is None else logdet
+        outs, ld = eng.encode(input, y_onehot, ld_in)
+        return outs[-1], (None if logdet is None else ld)
+    # reverse: log-det bookkeeping of a lone layer is not needed by any caller of the hot path
+    e = None if eps is None else {0: eps}
+    out = eng.decode_single(input, y_onehot, temperature, e)
+    return out, logdet
