@@ -157,17 +157,17 @@ class InvertibleConv1x1(nn.Module):
         super().__init__()
         self.is_1d = is_1d
         w_shape = [num_channels, num_channels]
-        w_init = torch.linalg.qr(torch.randn(*w_shape))[0]
+        w_init = torch.linalg.qr(torch.randn(*w_shape))[0].contiguous()
         if not LU_decomposed:
             self.weight = nn.Parameter(w_init.clone())
         else:
             p, lower, upper = torch.linalg.lu(w_init)
             s = torch.diag(upper)
-            self.register_buffer("p", p)
-            self.register_buffer("sign_s", torch.sign(s))
-            self.lower = nn.Parameter(lower)
-            self.log_s = nn.Parameter(torch.log(torch.abs(s)))
-            self.upper = nn.Parameter(torch.triu(upper, 1))
+            self.register_buffer("p", p.contiguous())
+            self.register_buffer("sign_s", torch.sign(s).contiguous())
+            self.lower = nn.Parameter(lower.contiguous())
+            self.log_s = nn.Parameter(torch.log(torch.abs(s)).contiguous())
+            self.upper = nn.Parameter(torch.triu(upper, 1).contiguous())
         self.w_shape = w_shape
         self.LU_decomposed = LU_decomposed
 
