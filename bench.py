@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Glow CIFAR-10 teacher(K=32) -> student(K=8) distillation training_step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = teacher forward (no grad) + student forward/backward + MSE hints on layer pairs
+[0,10,20,28]/[0,34,68,100] + global-norm clip 30 + Adam, on a synthetic
+CIFAR-shaped batch of 64 images per GPU already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N=1 only):
+  roofline     : K more steps with the GEMM launchers bracketed by HIP events (nfk_profile_*),
+                 dominant kernel's algorithmic FLOP/s against the f32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline : the CPU oracle (oracle/glow_oracle.py, a checked restatement of the reference)
+                 running the same step on the host cores for a bounded number of steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def cifar_cfg(K):
+    return dict(image_shape=[32, 32, 3], hidden_channels=512, K=K, L=3, actnorm_scale=1.0,
+                flow_permutation="invconv", flow_coupling="affine", LU_decomposed=True, y_classes=10,
+                learn_top=False, y_condition=False, is_1d=False)
+
+
+def make_models(device):
+    import nf_distillation_amd as nfa
+    from param_util import randomize_state_dict, shapes_of
+    models = []
+    for K, seed in ((8, 11), (32, 12)):
+        m = nfa.create_glow_model(cifar_cfg(K))
+        m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), seed))
+        models.append(m.to(device))
+    return models  # student, teacher
+
+
+def cpu_baseline(batch, steps):
+    """The oracle's distill_step on the host: 1 warm-up + `steps` timed steps."""
+    from oracle import glow_oracle as O
+    from param_util import randomize_state_dict, synthetic_images
+    from test_oracle_golden import full_shapes
+    s_cfg, t_cfg = cifar_cfg(8), cifar_cfg(32)
+    s_sd = randomize_state_dict(full_shapes(s_cfg), 11)
+    t_sd = randomize_state_dict(full_shapes(t_cfg), 12)
+    state = {}
+    times = []
+    for i in range(steps + 1):
+        x, noise = synthetic_images(batch, seed=100 + i)
+        t0 = time.perf_counter()
+        O.distill_step(s_sd, s_cfg, t_sd, t_cfg, x, noise, noise.clone(), state)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (after 1 warm-up) of the same distillation step, B={batch}, fp32, "
+                      f"torch CPU {torch.__version__}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    from nf_distillation_amd.dist import max_over_ranks
+    from nf_distillation_amd.training import DistillationStep
+    from nf_distillation_amd import capi
+    from param_util import synthetic_images
+
+    student, teacher = make_models(device)
+    step = DistillationStep(student, teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
+
+    # synthetic data, resident in HBM before the timed region; a few distinct batches, cycled
+    nb = 4
+    data = [synthetic_images(args.batch, seed=1000 + 17 * rank + i)[0].to(device) for i in range(nb)]
+
+    def run(n):
+        last = None
+        for i in range(n):
+            x = data[i % nb].clone()
+            last = step.training_step(x)
+        return last
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+
+    images = args.batch * world * args.steps
+    result = {
+        "metric": "train images/sec Glow CIFAR-10 distillation step",
+        "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Glow CIFAR-10 32x32 distillation training_step: teacher L=3 K=32 h=512 fwd (no grad) + "
+                               "student L=3 K=8 h=512 fwd+bwd + MSE hints + clip 30 + Adam",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+        "student_bpd": float(last["nll"]), "loss": float(last["result_loss"]),
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        capi.profile_begin()
+        run(args.steps)
+        prof = capi.profile_end()
+        dom = max(prof, key=lambda d: d["ms"])
+        avg_ms = dom["ms"] / max(dom["launches"], 1)
+        achieved = dom["flops"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "kernel": dom["kernel"], "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "launches_per_step": dom["launches"] / args.steps, "avg_launch_us": 1e3 * avg_ms,
+            "algorithmic_gflop_per_launch": dom["flops"] / max(dom["launches"], 1) / 1e9,
+            "gemm_ms_per_step": {d["kernel"]: d["ms"] / args.steps for d in prof},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_steps)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,6 +169,16 @@ int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const 
                   float gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   void *stream);
 
+/* ---- optional kernel timing (bench.py roofline leg) ------------------------------------------
+ * Between begin/end every GEMM-engine launch is bracketed by hipEvents on its own stream and
+ * attributed to a kernel class; `end` synchronises the device and returns, per class, total
+ * milliseconds, launches, algorithmic FLOPs (2*M*N*K) and algorithmic bytes.  Arrays of
+ * NFK_PROF_CLASSES. */
+enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW = 2, NFK_PROF_WGRAD_WIDE = 3,
+       NFK_PROF_WGRAD_NARROW = 4, NFK_PROF_CLASSES = 5 };
+void nfk_profile_begin(void);
+void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
+
 const char *nfk_version(void);
 
 #ifdef __cplusplus

@@ -68,6 +68,9 @@ i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long
 
 _PROTOS = {
     "nfk_version": (C.c_char_p, []),
+    "nfk_profile_begin": (None, []),
+    "nfk_profile_end": (None, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]),
     "nfk_padded_k": (i32, [i32]),
     "nfk_conv_splitk": (i32, [i32, i32, i32]),
     "nfk_chanmix_blocks": (i32, [i32]),
@@ -115,6 +118,22 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
+                "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>")
+
+
+def profile_begin():
+    lib().nfk_profile_begin()
+
+
+def profile_end():
+    """-> list of dicts per kernel class: ms, launches, flops, bytes."""
+    n = len(PROF_CLASSES)
+    ms, la, fl, by = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)(), (C.c_double * n)()
+    lib().nfk_profile_end(ms, la, fl, by)
+    return [dict(kernel=PROF_CLASSES[i], ms=ms[i], launches=la[i], flops=fl[i], bytes=by[i]) for i in range(n)]
 
 
 def exported_symbols():

@@ -56,6 +56,11 @@ ConvGemmArgs conv_args(const float* X, int ldx, int B, int H, int W, int Cin, in
 
 extern "C" {
 
+void nfk_profile_begin(void) { prof_begin(); }
+void nfk_profile_end(double* ms, long long* launches, double* flops, double* bytes) {
+  prof_end(ms, launches, flops, bytes);
+}
+
 const char* nfk_version(void) { return "nfk 0.1 (gfx950, f32 MFMA)"; }
 
 int nfk_padded_k(int K) { return padded_k(K); }

@@ -15,6 +15,7 @@
 // The accumulator then holds 4 consecutive channels of one pixel per lane, so epilogues are
 // float4-wide and per-channel parameters load as float4.
 #include "nfk_internal.h"
+#include <vector>
 
 namespace nfk {
 
@@ -439,10 +440,65 @@ __global__ void wgrad_finalize_kernel(const float* __restrict__ slabs, int S, lo
 }
 
 // ------------------------------------------------------------------------------------------
+// optional per-kernel-class timing with HIP events (bench.py's roofline leg); off by default
+// ------------------------------------------------------------------------------------------
+struct ProfClass {
+  std::vector<hipEvent_t> ev;   // start/stop pairs
+  size_t used = 0;
+  double flops = 0.0, bytes = 0.0;
+};
+static bool g_prof_on = false;
+static ProfClass g_prof[NFK_PROF_CLASSES];
+
+struct ProfScope {
+  ProfClass* c = nullptr;
+  hipStream_t st;
+  ProfScope(int cls, double flops, double bytes, hipStream_t s) : st(s) {
+    if (!g_prof_on) return;
+    c = &g_prof[cls];
+    if (c->used + 2 > c->ev.size()) {
+      c->ev.resize(c->used + 2);
+      (void)hipEventCreate(&c->ev[c->used]);
+      (void)hipEventCreate(&c->ev[c->used + 1]);
+    }
+    c->flops += flops;
+    c->bytes += bytes;
+    (void)hipEventRecord(c->ev[c->used], st);
+  }
+  ~ProfScope() {
+    if (!c) return;
+    (void)hipEventRecord(c->ev[c->used + 1], st);
+    c->used += 2;
+  }
+};
+
+void prof_begin() {
+  for (auto& c : g_prof) { c.used = 0; c.flops = 0.0; c.bytes = 0.0; }
+  g_prof_on = true;
+}
+// ms/launches/flops/bytes: arrays of NFK_PROF_CLASSES
+void prof_end(double* ms, long long* launches, double* flops, double* bytes) {
+  g_prof_on = false;
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < NFK_PROF_CLASSES; ++i) {
+    double t = 0.0;
+    for (size_t k = 0; k + 1 < g_prof[i].used; k += 2) {
+      float e = 0.f;
+      (void)hipEventElapsedTime(&e, g_prof[i].ev[k], g_prof[i].ev[k + 1]);
+      t += e;
+    }
+    ms[i] = t;
+    launches[i] = (long long)(g_prof[i].used / 2);
+    flops[i] = g_prof[i].flops;
+    bytes[i] = g_prof[i].bytes;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 template <int TN, int TM, int WN, int WM>
-static int launch_conv(const ConvGemmArgs& a, int S, hipStream_t st) {
+static int launch_conv(const ConvGemmArgs& a, int S, hipStream_t st, int cls) {
   constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
   constexpr size_t lds = 2 * (BN + BM) * LS * sizeof(float);
   static bool attr_set = false;
@@ -453,13 +509,15 @@ static int launch_conv(const ConvGemmArgs& a, int S, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(ceil_div(a.N, BN) * ceil_div(a.M, BM), S);
+  ProfScope ps(cls, 2.0 * a.M * (double)a.N * a.K,
+               4.0 * ((double)a.M * a.Cin + (double)a.N * a.K + (double)S * a.M * a.N), st);
   hipLaunchKernelGGL((conv_gemm_kernel<TN, TM, WN, WM>), grid, dim3(256), lds, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
 
 template <int TN, int TM, int WN, int WM>
-static int launch_wgrad(const WgradArgs& a, int S, hipStream_t st) {
+static int launch_wgrad(const WgradArgs& a, int S, hipStream_t st, int cls) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
   constexpr size_t lds = 2 * (BI + BJ) * LS * sizeof(float);
   static bool attr_set = false;
@@ -470,6 +528,8 @@ static int launch_wgrad(const WgradArgs& a, int S, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(ceil_div(a.NI, BI) * ceil_div(a.J, BJ), S);
+  ProfScope ps(cls, 2.0 * a.M * (double)a.NI * a.J,
+               4.0 * ((double)a.M * a.NI + (double)a.M * a.Cq + (double)S * a.NI * a.J), st);
   hipLaunchKernelGGL((wgrad_kernel<TN, TM, WN, WM>), grid, dim3(256), lds, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
@@ -506,14 +566,14 @@ int conv_gemm(ConvGemmArgs a, hipStream_t st) {
   const int S = conv_splitk(a.M, a.N, a.K, a.epi);
   if (a.N > 96) {
     const bool big = (long)ceil_div(a.N, 128) * ceil_div(a.M, 128) >= 256;
-    return big ? launch_conv<4, 4, 2, 2>(a, S, st) : launch_conv<2, 2, 2, 2>(a, S, st);
+    return big ? launch_conv<4, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128) : launch_conv<2, 2, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE64);
   }
   switch (ceil_div(a.N, 16)) {
-    case 1: return launch_conv<1, 2, 1, 4>(a, S, st);
-    case 2: return launch_conv<2, 2, 1, 4>(a, S, st);
-    case 3: return launch_conv<3, 2, 1, 4>(a, S, st);
-    case 4: return launch_conv<4, 2, 1, 4>(a, S, st);
-    default: return launch_conv<6, 2, 1, 4>(a, S, st);
+    case 1: return launch_conv<1, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    case 2: return launch_conv<2, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    case 3: return launch_conv<3, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    case 4: return launch_conv<4, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    default: return launch_conv<6, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
   }
 }
 
@@ -531,13 +591,13 @@ int wgrad_gemm(WgradArgs a, int S, hipStream_t st) {
   a.M = a.B * a.H * a.W;
   a.J = a.taps * a.Cq;
   if (a.M <= 0 || a.NI <= 0 || a.J <= 0) return NFK_OK;
-  if (a.NI > 96) return launch_wgrad<4, 4, 2, 2>(a, S, st);
+  if (a.NI > 96) return launch_wgrad<4, 4, 2, 2>(a, S, st, NFK_PROF_WGRAD_WIDE);
   switch (ceil_div(a.NI, 16)) {
-    case 1: return launch_wgrad<1, 2, 1, 4>(a, S, st);
-    case 2: return launch_wgrad<2, 2, 1, 4>(a, S, st);
-    case 3: return launch_wgrad<3, 2, 1, 4>(a, S, st);
-    case 4: return launch_wgrad<4, 2, 1, 4>(a, S, st);
-    default: return launch_wgrad<6, 2, 1, 4>(a, S, st);
+    case 1: return launch_wgrad<1, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    case 2: return launch_wgrad<2, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    case 3: return launch_wgrad<3, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    case 4: return launch_wgrad<4, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    default: return launch_wgrad<6, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
   }
 }
 

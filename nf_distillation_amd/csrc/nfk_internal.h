@@ -104,6 +104,8 @@ struct PriorBwdArgs {
   int HW, C; float bpd_scale;
 };
 
+void prof_begin();
+void prof_end(double* ms, long long* launches, double* flops, double* bytes);
 int padded_k(int K);
 int conv_splitk(int M, int N, int K, int epi);
 int conv_mblocks(int M, int N);

@@ -50,6 +50,7 @@ class FlowEngine:
         self.key = None
         self.is_1d = any(isinstance(l, M.FlowStep) and l.is_1d for l in layers)
         self._params = None
+        self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
 
     # ------------------------------------------------------------------ parameters
     def params(self):
@@ -487,6 +488,8 @@ class _EncodeFn(torch.autograd.Function):
                 check(lib.nfk_step2d_bwd(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
                                          ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws), s), "nfk_step2d_bwd")
                 g = gx
+                if eng.grad_hook is not None:
+                    eng.grad_hook(r.idx)
             elif r.kind == "split":
                 x_in, hs = sv
                 cz = r.mod.conv
@@ -497,6 +500,8 @@ class _EncodeFn(torch.autograd.Function):
                                           ptr(cz.conv.weight.grad), ptr(cz.conv.bias.grad), ptr(cz.logs.grad), ptr(ws), s),
                       "nfk_split2d_bwd")
                 g = gx
+                if eng.grad_hook is not None:
+                    eng.grad_hook(r.idx)
             else:  # squeeze: grad of the input = unsqueeze of the grad
                 tot = g if ext is None else (ext if g is None else g + ext)
                 first = r is recs[0]
