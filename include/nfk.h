@@ -69,7 +69,7 @@ typedef struct nfk_step2d {
 
 typedef struct nfk_step2d_grads {   /* all accumulate (+=) */
   float *g_w1, *g_b1, *g_l1, *g_w2, *g_b2, *g_l2, *g_w3, *g_bias3, *g_l3;
-  float *mix_part;                  /* [nfk_chanmix_blocks(M)][C*C + C], consumed by nfk_prep_bwd */
+  float *mix_part;                  /* [nfk_chanmix_blocks(M, C)][C*C + C], consumed by nfk_prep_bwd */
 } nfk_step2d_grads;
 
 /* Split2d (models/layers.py:293-313): Conv2dZeros(C/2 -> C) prior on the dropped half. */
@@ -95,7 +95,7 @@ typedef struct nfk_small_grad_args {
 /* ---- sizes ------------------------------------------------------------------------------- */
 int nfk_padded_k(int K);                          /* K rounded up to the k-chunk (32)            */
 int nfk_conv_splitk(int M, int N, int K);         /* slabs written by a raw-output conv          */
-int nfk_chanmix_blocks(int M);
+int nfk_chanmix_blocks(int M, int C);         /* partial (gWf,gcf) slabs a step backward writes  */
 size_t nfk_step2d_fwd_ws_floats(const nfk_step2d *s);   /* a3 slab workspace                   */
 size_t nfk_step2d_bwd_ws_floats(const nfk_step2d *s);
 size_t nfk_split2d_fwd_ws_floats(const nfk_split2d *s);

@@ -73,7 +73,7 @@ _PROTOS = {
                                C.POINTER(C.c_double)]),
     "nfk_padded_k": (i32, [i32]),
     "nfk_conv_splitk": (i32, [i32, i32, i32]),
-    "nfk_chanmix_blocks": (i32, [i32]),
+    "nfk_chanmix_blocks": (i32, [i32, i32]),
     "nfk_step2d_fwd_ws_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_bwd_ws_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_split2d_fwd_ws_floats": (u64, [C.POINTER(Split2d)]),

@@ -65,7 +65,7 @@ const char* nfk_version(void) { return "nfk 0.1 (gfx950, f32 MFMA)"; }
 
 int nfk_padded_k(int K) { return padded_k(K); }
 int nfk_conv_splitk(int M, int N, int K) { return conv_splitk(M, N, K, EPI_RAW); }
-int nfk_chanmix_blocks(int M) { return chanmix_blocks(M); }
+int nfk_chanmix_blocks(int M, int C) { return chanmix_parts(M, C); }
 
 size_t nfk_step2d_fwd_ws_floats(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;

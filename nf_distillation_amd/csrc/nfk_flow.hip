@@ -269,71 +269,91 @@ __global__ void __launch_bounds__(256) prep_bwd_dense_kernel(const PrepDesc* __r
 // ==========================================================================================
 // chanmix:  z[m][o] = sum_c Wm[o][c] x[m][c] + cv[o]      (trans: uses Wm[c][o], no cv)
 // ==========================================================================================
-constexpr int CM_TP = 64;  // pixels per workgroup
+constexpr int CM_MAX_BLOCKS = 64;  // backward: at most this many partial (gWf, gcf) slabs per step
 
+// pixels per tile: TP * ceil(C/4) output-groups ~ 256 threads
+static inline __host__ __device__ int cm_tile_pixels(int C) {
+  const int g4 = (C + 3) / 4;
+  int tp = 64;
+  while (tp > 1 && tp * g4 > 256) tp >>= 1;
+  return tp;
+}
 
 __global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = a.C, Cp = (C + 3) & ~3, XS = C + 1;
+  const int C = a.C, Cp = (C + 3) & ~3, XS = C + 1, G4 = Cp / 4;
+  const int TP = cm_tile_pixels(C);
   float* Wl = smem;                 // [C][Cp]  stored [in][out]
   float* Xl = Wl + C * Cp;          // [TP][C+1]
-  float* Gl = Xl + CM_TP * XS;      // [TP][C+1] (backward: x_in tile)
-  const int m0 = blockIdx.x * CM_TP;
+  float* Gl = Xl + TP * XS;         // [TP][C+1] (backward: x_in tile)
+  float* Pl = Gl + TP * XS;         // [C*C + C] (backward: partial sums, each element owned by one thread)
+  const int E = C * C + C;
   for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
-    const int r = idx / C, q = idx % C;  // Wm[r][q]
+    const int r = idx / C, q = idx - r * C;  // Wm[r][q]
     if (a.trans) Wl[r * Cp + q] = a.Wm[idx];      // in = r (rows of Wm), out = q
     else Wl[q * Cp + r] = a.Wm[idx];               // in = q, out = r
   }
-  for (int idx = threadIdx.x; idx < CM_TP * C; idx += blockDim.x) {
-    const int p = idx / C, c = idx % C, m = m0 + p;
-    float v = 0.f;
-    if (m < a.M) {
-      if (a.ga && c < a.Ch) {
-        v = a.ga[(long)m * a.lda + c];
-        if (a.gext) v += a.gext[(long)m * a.ldge + c];
-        for (int s = 0; s < a.S; ++s) v += a.slab[s * a.slab_stride + (long)m * a.Ch + c];
-      } else {
-        v = a.x[(long)m * a.ldx + c];
+  if (a.part)
+    for (int idx = threadIdx.x; idx < E; idx += blockDim.x) Pl[idx] = 0.f;
+  const int ntiles = (a.M + TP - 1) / TP;
+  const int p = threadIdx.x / G4, og = threadIdx.x - p * G4;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * TP;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TP * C; idx += blockDim.x) {
+      const int pp = idx / C, c = idx - pp * C, m = m0 + pp;
+      float v = 0.f;
+      if (m < a.M) {
+        if (a.ga && c < a.Ch) {
+          v = a.ga[(long)m * a.lda + c];
+          if (a.gext) v += a.gext[(long)m * a.ldge + c];
+          for (int s = 0; s < a.S; ++s) v += a.slab[s * a.slab_stride + (long)m * a.Ch + c];
+        } else {
+          v = a.x[(long)m * a.ldx + c];
+        }
+      }
+      Xl[pp * XS + c] = v;
+      if (a.part) Gl[pp * XS + c] = m < a.M ? a.xin[(long)m * a.ldxin + c] : 0.f;
+    }
+    __syncthreads();
+    if (p < TP) {
+      const int o = og * 4, m = m0 + p;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (a.cv)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < C) acc[r] = a.cv[o + r];
+      const float* xr = Xl + p * XS;
+      for (int c = 0; c < C; ++c) {
+        const float xv = xr[c];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+      }
+      if (m < a.M) {
+        float* zp = a.z + (long)m * a.ldz + o;
+        if (o + 3 < C && (a.ldz & 3) == 0) *reinterpret_cast<f32x4*>(zp) = acc;
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (o + r < C) zp[r] = acc[r];
       }
     }
-    Xl[p * XS + c] = v;
-    if (a.part) Gl[p * XS + c] = m < a.M ? a.xin[(long)m * a.ldxin + c] : 0.f;
-  }
-  __syncthreads();
-  const int p = threadIdx.x & (CM_TP - 1), og = threadIdx.x / CM_TP, ngroups = blockDim.x / CM_TP;
-  const int m = m0 + p;
-  for (int o = og * 4; o < C; o += ngroups * 4) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (a.cv)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) if (o + r < C) acc[r] = a.cv[o + r];
-    for (int c = 0; c < C; ++c) {
-      const float xv = Xl[p * XS + c];
-      const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp + o);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
-    }
-    if (m < a.M) {
-      float* zp = a.z + (long)m * a.ldz + o;
-      if (o + 3 < C && (a.ldz & 3) == 0) *reinterpret_cast<f32x4*>(zp) = acc;
-      else
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (o + r < C) zp[r] = acc[r];
+    if (a.part) {
+      for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
+        float s = 0.f;
+        if (idx < C * C) {
+          const int o = idx / C, c = idx - o * C;
+          for (int q = 0; q < TP; ++q) s += Xl[q * XS + o] * Gl[q * XS + c];
+        } else {
+          const int o = idx - C * C;
+          for (int q = 0; q < TP; ++q) s += Xl[q * XS + o];
+        }
+        Pl[idx] += s;
+      }
     }
   }
   if (a.part) {
-    float* part = a.part + (long)blockIdx.x * (C * C + C);
-    for (int idx = threadIdx.x; idx < C * C + C; idx += blockDim.x) {
-      float s = 0.f;
-      if (idx < C * C) {
-        const int o = idx / C, c = idx % C;
-        for (int q = 0; q < CM_TP; ++q) s += Xl[q * XS + o] * Gl[q * XS + c];
-      } else {
-        const int o = idx - C * C;
-        for (int q = 0; q < CM_TP; ++q) s += Xl[q * XS + o];
-      }
-      part[idx] = s;
-    }
+    float* part = a.part + (long)blockIdx.x * E;
+    for (int idx = threadIdx.x; idx < E; idx += blockDim.x) part[idx] = Pl[idx];
   }
 }
 
@@ -347,7 +367,7 @@ __device__ __forceinline__ float slab_sum(const float* a3, int S, long stride, l
   return v;
 }
 
-__global__ void __launch_bounds__(256) coupling_fwd_kernel(CouplingArgs a) {
+__global__ void __launch_bounds__(1024) coupling_fwd_kernel(CouplingArgs a) {
   __shared__ float sh[32];
   const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
   const long mb = (long)b * a.HW;
@@ -382,7 +402,7 @@ __global__ void __launch_bounds__(256) coupling_fwd_kernel(CouplingArgs a) {
 }
 
 // inverse: given the step OUTPUT y = (z1 | z2'), recover the mixed z = (z1 | z2)
-__global__ void __launch_bounds__(256) coupling_inv_kernel(CouplingArgs a) {
+__global__ void __launch_bounds__(1024) coupling_inv_kernel(CouplingArgs a) {
   __shared__ float sh[32];
   const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
   const long mb = (long)b * a.HW;
@@ -655,22 +675,31 @@ __global__ void __launch_bounds__(256) prior_bwd_kernel(PriorBwdArgs a) {
 // Finalise the small per-channel parameter gradients of one coupling net (accumulates):
 //   colsum layout from conv_gemm EPI_DGRAD: [mblocks][2][N] = (sum acc*h , sum masked*scale)
 //   tail layout from coupling_bwd / split_bwd: [B][2][Cout] = (sum g_a3, 3 sum g_h h)
-__global__ void small_grads_kernel(SmallGradArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < a.n1) {
-    float dl = 0.f, db = 0.f;
-    for (int i = 0; i < a.mb1; ++i) { dl += a.col1[((long)i * 2) * a.n1 + t]; db += a.col1[((long)i * 2 + 1) * a.n1 + t]; }
-    a.g_l1[t] += dl; a.g_b1[t] += db;
-  }
-  if (t < a.n2) {
-    float dl = 0.f, db = 0.f;
-    for (int i = 0; i < a.mb2; ++i) { dl += a.col2[((long)i * 2) * a.n2 + t]; db += a.col2[((long)i * 2 + 1) * a.n2 + t]; }
-    a.g_l2[t] += dl; a.g_b2[t] += db;
-  }
-  if (t < a.n3) {
-    float db = 0.f, dl = 0.f;
-    for (int i = 0; i < a.B; ++i) { db += a.tail[((long)i * 2) * a.n3 + t]; dl += a.tail[((long)i * 2 + 1) * a.n3 + t]; }
-    a.g_bias3[t] += db; a.g_l3[t] += dl;
+// One block = 32 columns x 8 row-groups; rows (partials) are summed per row-group, then over the
+// 8 groups in fixed order through LDS.  blockIdx.y selects the segment (layer-1, layer-2, tail).
+__global__ void __launch_bounds__(256) small_grads_kernel(SmallGradArgs a) {
+  __shared__ float red[2][8][32];
+  const int seg = blockIdx.y;
+  const float* src; int rows, n; float *g0, *g1;
+  if (seg == 0) { src = a.col1; rows = a.mb1; n = a.n1; g0 = a.g_l1; g1 = a.g_b1; }
+  else if (seg == 1) { src = a.col2; rows = a.mb2; n = a.n2; g0 = a.g_l2; g1 = a.g_b2; }
+  else { src = a.tail; rows = a.B; n = a.n3; g0 = a.g_bias3; g1 = a.g_l3; }
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  if (blockIdx.x * 32 >= n) return;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < n)
+    for (int i = rg; i < rows; i += 8) {
+      s0 += src[((long)i * 2) * n + col];
+      s1 += src[((long)i * 2 + 1) * n + col];
+    }
+  red[0][rg][threadIdx.x & 31] = s0;
+  red[1][rg][threadIdx.x & 31] = s1;
+  __syncthreads();
+  if (rg < 2 && col < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[rg][k][threadIdx.x & 31];
+    (rg == 0 ? g0 : g1)[col] += t;
   }
 }
 
@@ -681,6 +710,9 @@ static inline int ew_blocks(long total) {
   long b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
+
+// threads for a one-workgroup-per-sample kernel over n elements
+static inline int sample_threads(int n) { return n >= 1024 ? 1024 : (n > 256 ? ((n + 63) / 64) * 64 : 256); }
 
 int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st) {
   if (nsteps <= 0) return NFK_OK;
@@ -702,8 +734,8 @@ int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int ns
 
 int launch_chanmix(const ChanMixArgs& a, hipStream_t st) {
   if (a.M <= 0) return NFK_OK;
-  const int C = a.C, Cp = (C + 3) & ~3;
-  const size_t lds = (size_t)(C * Cp + 2 * CM_TP * (C + 1)) * sizeof(float);
+  const int C = a.C, Cp = (C + 3) & ~3, TP = cm_tile_pixels(C);
+  const size_t lds = (size_t)(C * Cp + 2 * TP * (C + 1) + (a.part ? C * C + C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return NFK_ERR_ARG;
   static bool attr = false;
   if (!attr) {
@@ -711,19 +743,25 @@ int launch_chanmix(const ChanMixArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(chanmix_kernel, dim3(ceil_div(a.M, CM_TP)), dim3(256), lds, st, a);
+  int blocks = ceil_div(a.M, TP);
+  if (a.part && blocks > CM_MAX_BLOCKS) blocks = CM_MAX_BLOCKS;  // == number of partial slabs written
+  hipLaunchKernelGGL(chanmix_kernel, dim3(blocks), dim3(256), lds, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
-int chanmix_blocks(int M) { return ceil_div(M, CM_TP); }
+// number of partial slabs nfk_step2d_bwd writes for (M, C)
+int chanmix_parts(int M, int C) {
+  const int b = ceil_div(M, cm_tile_pixels(C));
+  return b < CM_MAX_BLOCKS ? b : CM_MAX_BLOCKS;
+}
 
 int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st) {
-  hipLaunchKernelGGL(coupling_fwd_kernel, dim3(B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3(B), dim3(sample_threads(a.HW * (a.C - a.C / 2))), 0, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
 int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st) {
-  hipLaunchKernelGGL(coupling_inv_kernel, dim3(B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(coupling_inv_kernel, dim3(B), dim3(sample_threads(a.HW * (a.C - a.C / 2))), 0, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
@@ -801,7 +839,7 @@ int launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
   int n = a.n1 > a.n2 ? a.n1 : a.n2;
   if (a.n3 > n) n = a.n3;
   if (n <= 0) return NFK_OK;
-  hipLaunchKernelGGL(small_grads_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(small_grads_kernel, dim3(ceil_div(n, 32), 3), dim3(256), 0, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

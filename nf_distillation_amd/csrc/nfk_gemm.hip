@@ -53,6 +53,33 @@ __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, con
   }
 }
 
+// Same MFMA schedule for tiles stored k-major: T[k][rows + 4 pad] (k = pixel), read with ds_read_b32.
+// MFMA jj of half kh consumes k = 16*kh + 4*(lane>>4) + jj on both operands.
+template <int TN, int TM>
+__device__ __forceinline__ void mfma_tile_step_kmajor(const float* __restrict__ As, int lda, const float* __restrict__ Bs,
+                                                      int ldb, int arow0, int brow0, int lane, f32x4 (&acc)[TN][TM]) {
+  const int r = lane & 15, kq = (lane >> 4) * 4;
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    f32x4 a[TN], b[TM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kh * 16 + kq + j;
+#pragma unroll
+      for (int t = 0; t < TN; ++t) a[t][j] = As[k * lda + arow0 + t * 16 + r];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) b[t][j] = Bs[k * ldb + brow0 + t * 16 + r];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tn][j], b[tm][j], acc[tn][tm], 0, 0, 0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // conv / dgrad kernel
 // ------------------------------------------------------------------------------------------
@@ -319,24 +346,21 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
       qreg[t] = v;
     }
   };
+  constexpr int LDP = BI + 4, LDQ = BJ + 4, STAGE = BK * (LDP + LDQ);
   auto lstore = [&](int buf) {
-    float* Ps = smem + buf * (BI + BJ) * LS;
-    float* Qs = Ps + BI * LS;
+    float* Ps = smem + buf * STAGE;
+    float* Qs = Ps + BK * LDP;
 #pragma unroll
     for (int t = 0; t < PL; ++t) {
       const int idx = tid + 256 * t;
       const int pl = idx / PG, g = idx % PG;
-      if (idx < BI * 8)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ps[(g * 4 + r) * LS + pl] = preg[t][r];
+      if (idx < BI * 8) *reinterpret_cast<f32x4*>(Ps + pl * LDP + g * 4) = preg[t];
     }
 #pragma unroll
     for (int t = 0; t < QL; ++t) {
       const int idx = tid + 256 * t;
       const int pl = idx / QG, g = idx % QG;
-      if (idx < BJ * 8)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Qs[(g * 4 + r) * LS + pl] = qreg[t][r];
+      if (idx < BJ * 8) *reinterpret_cast<f32x4*>(Qs + pl * LDQ + g * 4) = qreg[t];
     }
   };
 
@@ -353,8 +377,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   for (int c = c_begin; c < c_end; ++c) {
     const int buf = (c - c_begin) & 1;
     if (c + 1 < c_end) gload(c + 1);
-    const float* Ps = smem + buf * (BI + BJ) * LS;
-    mfma_tile_step<TN, TM>(Ps, Ps + BI * LS, wn * 16 * TN, wm * 16 * TM, lane, acc);
+    const float* Ps = smem + buf * STAGE;
+    mfma_tile_step_kmajor<TN, TM>(Ps, LDP, Ps + BK * LDP, LDQ, wn * 16 * TN, wm * 16 * TM, lane, acc);
     if (c + 1 < c_end) lstore(buf ^ 1);
     __syncthreads();
   }
@@ -519,7 +543,7 @@ static int launch_conv(const ConvGemmArgs& a, int S, hipStream_t st, int cls) {
 template <int TN, int TM, int WN, int WM>
 static int launch_wgrad(const WgradArgs& a, int S, hipStream_t st, int cls) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
-  constexpr size_t lds = 2 * (BI + BJ) * LS * sizeof(float);
+  constexpr size_t lds = 2 * BK * (BI + BJ + 8) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 48 * 1024)

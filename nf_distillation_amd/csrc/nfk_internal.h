@@ -120,7 +120,7 @@ int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStre
 int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
                     int any_dense, hipStream_t st);
 int launch_chanmix(const ChanMixArgs& a, hipStream_t st);
-int chanmix_blocks(int M);
+int chanmix_parts(int M, int C);
 int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st);
 int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st);
 int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);

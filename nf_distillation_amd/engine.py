@@ -463,7 +463,7 @@ class _EncodeFn(torch.autograd.Function):
         part_off, total = {}, 0
         for r in recs:
             if r.kind == "step":
-                nb = lib.nfk_chanmix_blocks(B * r.H * r.W)
+                nb = lib.nfk_chanmix_blocks(B * r.H * r.W, r.C)
                 part_off[r.idx] = (total, nb)
                 total += _a4(nb * (r.C * r.C + r.C))
         parts = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
