@@ -79,6 +79,21 @@ typedef struct nfk_split2d {
   const float *wt, *wd;             /* repacked weights */
 } nfk_split2d;
 
+/* One 1-D (tabular) FlowStep: ActNorm1d + x @ W + get_block_1d MLP + coupling tail
+ * (models/flows.py:37-52, 142-202 with is_1d).  W[l]/b[l] are the nn.Linear weights [out][in] / biases of
+ * block.{0,2,4,6,8,10}; Wf/cf/Wi/ci/dld come from nfk_prep. */
+typedef struct nfk_tab_step {
+  int32_t B, d, hid, ncond, additive, pad_;
+  const float *W[6];
+  const float *b[6];
+  const float *Wf, *cf, *Wi, *ci, *dld;
+} nfk_tab_step;
+
+typedef struct nfk_tab_grads { /* accumulate (+=) */
+  float *gW[6];
+  float *gb[6];
+} nfk_tab_grads;
+
 /* One conv weight to repack (see nfk_repack); DEVICE array for nfk_repack_batch. */
 typedef struct nfk_repack_desc {
   const float *w;
@@ -160,6 +175,20 @@ int nfk_split2d_inv(const nfk_split2d *s, const float *z1, const float *eps, flo
 int nfk_split2d_bwd(const nfk_split2d *s, const float *x, const float *hsave, const float *g_z1,
                     const float *g_ext, const float *g_ld, float *g_x, float *g_w, float *g_bias,
                     float *g_logs, float *ws, void *stream);
+
+/* ---- 1-D (tabular) FlowStep: one fused kernel per direction ----------------------------------- */
+int nfk_tab_bwd_blocks(const nfk_tab_step *s);    /* slabs of `part` / `part_mix` the backward writes */
+int nfk_tab_param_floats(const nfk_tab_step *s);  /* floats per `part` slab                            */
+/* FlowStep.normal_flow, 1-D: x [B][d] (+ cond [B][ncond] or NULL) -> zout, ld_out = ld_in + dlogdet */
+int nfk_tab_fwd(const nfk_tab_step *s, const float *x, const float *cond, const float *ld_in, float *zout,
+                float *ld_out, void *stream);
+/* FlowStep.reverse_flow, 1-D: y -> x (ld_* may be NULL) */
+int nfk_tab_inv(const nfk_tab_step *s, const float *y, const float *cond, const float *ld_in, float *xout,
+                float *ld_out, void *stream);
+/* backward: recomputes the forward per row tile in LDS; part [blocks][param_floats], part_mix [blocks][d*d+d] */
+int nfk_tab_bwd(const nfk_tab_step *s, const nfk_tab_grads *g, const float *x, const float *cond,
+                const float *g_out, const float *g_ld, float *g_x, float *g_cond, float *part, float *part_mix,
+                void *stream);
 
 /* ---- optimiser (torch.optim.Adam + clip_grad_norm_, pl_module.py:350-354, train.py:46) ------ */
 /* sumsq[0] += sum g^2 over n elements (deterministic two-stage tree); partial: >= 1024 floats */

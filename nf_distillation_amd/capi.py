@@ -59,6 +59,17 @@ class Split2d(C.Structure):
                 ("bias", c_fp), ("es", c_fp), ("wt", c_fp), ("wd", c_fp)]
 
 
+class TabStepC(C.Structure):
+    _fields_ = [("B", C.c_int32), ("d", C.c_int32), ("hid", C.c_int32), ("ncond", C.c_int32),
+                ("additive", C.c_int32), ("pad_", C.c_int32),
+                ("W", c_fp * 6), ("b", c_fp * 6),
+                ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp)]
+
+
+class TabGrads(C.Structure):
+    _fields_ = [("gW", c_fp * 6), ("gb", c_fp * 6)]
+
+
 class RepackDesc(C.Structure):
     _fields_ = [("w", c_fp), ("wt", c_fp), ("wd", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
                 ("taps", C.c_int32), ("pad_", C.c_int32)]
@@ -97,6 +108,11 @@ _PROTOS = {
     "nfk_split2d_fwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp]),
     "nfk_split2d_inv": (i32, [C.POINTER(Split2d), vp, vp, f32, vp, vp, vp]),
     "nfk_split2d_bwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_tab_bwd_blocks": (i32, [C.POINTER(TabStepC)]),
+    "nfk_tab_param_floats": (i32, [C.POINTER(TabStepC)]),
+    "nfk_tab_fwd": (i32, [C.POINTER(TabStepC), vp, vp, vp, vp, vp, vp]),
+    "nfk_tab_inv": (i32, [C.POINTER(TabStepC), vp, vp, vp, vp, vp, vp]),
+    "nfk_tab_bwd": (i32, [C.POINTER(TabStepC), C.POINTER(TabGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_sumsq": (i32, [vp, u64, vp, vp, vp]),
     "nfk_adam_step": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
 }

@@ -1,2 +1,422 @@
-// 1-D (tabular) fused FlowStep kernels -- see below.
+// nfk tabular kernels: one fused kernel per direction for the reference's 1-D FlowStep
+// (models/flows.py:142-202 with is_1d: ActNorm1d -> x @ W -> 6-layer MLP coupling net
+// get_block_1d models/flows.py:37-52 -> affine/additive tail -> per-row log-det).
+//
+// A workgroup owns a tile of TR rows; every layer's activations for the tile live in LDS, the
+// current layer's weights are staged (transposed) in LDS, thread = (row, 4 outputs).  Nothing but
+// the step input and output touches HBM.  The backward kernel recomputes the tile's forward into
+// LDS (cheaper than saving 7 activations per row), back-propagates layer by layer and
+// accumulates weight-gradient partial sums in LDS; one slab per workgroup is written and reduced
+// in fixed order by tab_reduce_kernel (deterministic, no atomics).
 #include "nfk_internal.h"
+
+namespace nfk {
+
+using TabStep = nfk_tab_step;
+
+__host__ __device__ static inline int pad4(int n) { return (n + 3) & ~3; }
+__host__ __device__ static inline int tab_rows(int hid, int d) {
+  int m = hid > d ? hid : d;
+  const int g4 = (m + 3) / 4;
+  int tr = 64;
+  while (tr > 1 && tr * g4 > 256) tr >>= 1;
+  return tr;
+}
+__host__ __device__ static inline int tab_nout(const TabStep& s) {
+  const int C2 = s.d - s.d / 2;
+  return s.additive ? C2 : 2 * C2;
+}
+__host__ __device__ static inline int tab_nin0(const TabStep& s) { return s.d / 2 + s.ncond; }
+__host__ __device__ static inline int tab_layer_in(const TabStep& s, int l) { return l == 0 ? tab_nin0(s) : s.hid; }
+__host__ __device__ static inline int tab_layer_out(const TabStep& s, int l) { return l == 5 ? tab_nout(s) : s.hid; }
+__host__ __device__ static inline int tab_param_floats(const TabStep& s) {
+  int t = 0;
+  for (int l = 0; l < 6; ++l) t += tab_layer_out(s, l) * (tab_layer_in(s, l) + 1);
+  return t;
+}
+
+__host__ __device__ static inline int tab_param_off(const TabStep& s, int l) {
+  int t = 0;
+  for (int k = 0; k < l; ++k) t += tab_layer_out(s, k) * (tab_layer_in(s, k) + 1);
+  return t;
+}
+
+struct TabLds {
+  int TR, XS, HS, OS, IS, GS;
+  float *X, *Y, *IN0, *H[5], *O, *GA, *GB, *GY, *Wl, *Pl, *PM;
+};
+
+__host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds* L, float* base) {
+  const int d = s.d, hid = s.hid, nout = tab_nout(s), nin0 = tab_nin0(s);
+  const int TR = tab_rows(hid, d);
+  int mx = d > hid ? d : hid;
+  if (nout > mx) mx = nout;
+  if (nin0 > mx) mx = nin0;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~size_t(3); return r; };
+  const int XS = d + 1, HS = hid + 1, OS = nout + 1, IS = nin0 + 1, GS = mx + 1;
+  size_t oX = take((size_t)TR * XS), oY = take((size_t)TR * XS), oI = take((size_t)TR * IS);
+  size_t oH[5];
+  for (int k = 0; k < 5; ++k) oH[k] = take((size_t)TR * HS);
+  size_t oO = take((size_t)TR * OS);
+  size_t oW = take((size_t)mx * pad4(mx));
+  size_t oGA = 0, oGB = 0, oGY = 0, oP = 0, oPM = 0;
+  if (bwd) {
+    oGA = take((size_t)TR * GS); oGB = take((size_t)TR * GS); oGY = take((size_t)TR * XS);
+    oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d);
+  }
+  if (L) {
+    L->TR = TR; L->XS = XS; L->HS = HS; L->OS = OS; L->IS = IS; L->GS = GS;
+    L->X = base + oX; L->Y = base + oY; L->IN0 = base + oI;
+    for (int k = 0; k < 5; ++k) L->H[k] = base + oH[k];
+    L->O = base + oO; L->Wl = base + oW;
+    L->GA = base + oGA; L->GB = base + oGB; L->GY = base + oGY; L->Pl = base + oP; L->PM = base + oPM;
+  }
+  return o * sizeof(float);
+}
+
+// out[p][o] = act(sum_c in[p][c] * Wm(o,c) + b[o]);  Wm(o,c) = W[o*nin + c]  (trans=0, nn.Linear)
+//                                                   or W[c*nout + o]         (trans=1: uses W^T)
+// act: 0 none, 1 relu, 2 tanh.  Block-wide; contains barriers.
+__device__ void tab_dense(const float* in, int ldi, int nin, const float* __restrict__ W, const float* __restrict__ b,
+                          float* out, int ldo, int nout, int act, int trans, float* Wl, int TR) {
+  const int np = pad4(nout);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nin * nout; idx += blockDim.x) {
+    if (trans) { const int c = idx / nout, o = idx - c * nout; Wl[c * np + o] = W[idx]; }
+    else { const int o = idx / nin, c = idx - o * nin; Wl[c * np + o] = W[idx]; }
+  }
+  __syncthreads();
+  const int G4 = np / 4;
+  for (int t = threadIdx.x; t < TR * G4; t += blockDim.x) {
+    const int p = t / G4, o = (t - p * G4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (o + r < nout) acc[r] = b[o + r];
+    const float* xr = in + p * ldi;
+    for (int c = 0; c < nin; ++c) {
+      const float xv = xr[c];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * np + o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (o + r < nout) {
+        float v = acc[r];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = tanhf(v);
+        out[p * ldo + o + r] = v;
+      }
+  }
+  __syncthreads();
+}
+
+// Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
+__device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0) {
+  const int d = s.d, Ch = d / 2, TR = L.TR;
+  for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+    const int p = idx / d, c = idx - p * d, m = row0 + p;
+    L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
+  }
+  tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
+  const int nin0 = tab_nin0(s);
+  for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+    const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+    float v;
+    if (c < Ch) v = L.Y[p * L.XS + c];
+    else v = m < s.B ? cond[(long)m * s.ncond + (c - Ch)] : 0.f;
+    L.IN0[p * L.IS + c] = v;
+  }
+  const float* in = L.IN0;
+  int ldi = L.IS;
+  for (int l = 0; l < 5; ++l) {
+    tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+    in = L.H[l];
+    ldi = L.HS;
+  }
+  tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+}
+
+__global__ void __launch_bounds__(256) tab_fwd_kernel(TabStep s, const float* __restrict__ x,
+                                                      const float* __restrict__ cond, const float* __restrict__ ld_in,
+                                                      float* __restrict__ zout, float* __restrict__ ld_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TabLds L;
+  tab_layout(s, false, &L, smem);
+  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR;
+  const int ntiles = (s.B + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TR;
+    tab_forward_tile(s, L, x, cond, row0);
+    // coupling tail; log-scale terms go to GA-less scratch: reuse X (no longer needed) as [TR][XS]
+    for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
+      const int p = idx / C2, j = idx - p * C2, m = row0 + p;
+      const float z2 = L.Y[p * L.XS + Ch + j];
+      float out, lt = 0.f;
+      if (s.additive) out = z2 + L.O[p * L.OS + j];
+      else {
+        const float t = L.O[p * L.OS + 2 * j + 1] + 2.f;
+        out = (z2 + L.O[p * L.OS + 2 * j]) * sigmoidf(t);
+        lt = log_sigmoidf(t);
+      }
+      L.X[p * L.XS + j] = lt;
+      if (m < s.B) zout[(long)m * d + Ch + j] = out;
+    }
+    for (int idx = threadIdx.x; idx < TR * Ch; idx += blockDim.x) {
+      const int p = idx / Ch, j = idx - p * Ch, m = row0 + p;
+      if (m < s.B) zout[(long)m * d + j] = L.Y[p * L.XS + j];
+    }
+    __syncthreads();
+    if (ld_out)
+      for (int p = threadIdx.x; p < TR; p += blockDim.x) {
+        const int m = row0 + p;
+        if (m < s.B) {
+          float t = 0.f;
+          for (int j = 0; j < C2; ++j) t += L.X[p * L.XS + j];
+          ld_out[m] = ld_in[m] + s.dld[0] + t;
+        }
+      }
+    __syncthreads();
+  }
+}
+
+// inverse: y (step output) -> x.  z1 = y[:Ch]; (shift, scale) = MLP(z1, cond); z2 = y2/scale - shift; x = Wi z + ci
+__global__ void __launch_bounds__(256) tab_inv_kernel(TabStep s, const float* __restrict__ y,
+                                                      const float* __restrict__ cond, const float* __restrict__ ld_in,
+                                                      float* __restrict__ xout, float* __restrict__ ld_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TabLds L;
+  tab_layout(s, false, &L, smem);
+  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s);
+  const int ntiles = (s.B + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TR;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      L.Y[p * L.XS + c] = m < s.B ? y[(long)m * d + c] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+      const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+      L.IN0[p * L.IS + c] = c < Ch ? L.Y[p * L.XS + c] : (m < s.B ? cond[(long)m * s.ncond + (c - Ch)] : 0.f);
+    }
+    const float* in = L.IN0;
+    int ldi = L.IS;
+    for (int l = 0; l < 5; ++l) {
+      tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+      in = L.H[l];
+      ldi = L.HS;
+    }
+    tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+    for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
+      const int p = idx / C2, j = idx - p * C2;
+      const float y2 = L.Y[p * L.XS + Ch + j];
+      float out, lt = 0.f;
+      if (s.additive) out = y2 - L.O[p * L.OS + j];
+      else {
+        const float t = L.O[p * L.OS + 2 * j + 1] + 2.f;
+        out = y2 * (1.f + expf(-t)) - L.O[p * L.OS + 2 * j];
+        lt = log_sigmoidf(t);
+      }
+      L.X[p * L.XS + j] = lt;            // log terms (X is free until the final mix)
+      L.Y[p * L.XS + Ch + j] = out;      // z = (z1 | z2) assembled in place (same thread reads and writes it)
+    }
+    __syncthreads();
+    if (ld_out)
+      for (int p = threadIdx.x; p < TR; p += blockDim.x) {
+        const int m = row0 + p;
+        if (m < s.B) {
+          float t = 0.f;
+          for (int j = 0; j < C2; ++j) t += L.X[p * L.XS + j];
+          ld_out[m] = ld_in[m] - s.dld[0] - t;
+        }
+      }
+    tab_dense(L.Y, L.XS, d, s.Wi, s.ci, L.X, L.XS, d, 0, 0, L.Wl, TR);
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      if (m < s.B) xout[(long)m * d + c] = L.X[p * L.XS + c];
+    }
+  }
+}
+
+// accumulate  P[o*(nin+1) + c] += sum_p g[p][o] * in[p][c]   and   P[o*(nin+1) + nin] += sum_p g[p][o]
+__device__ void tab_wgrad(const float* g, int ldg, const float* in, int ldi, int nin, int nout, float* P, int TR) {
+  for (int idx = threadIdx.x; idx < nout * (nin + 1); idx += blockDim.x) {
+    const int o = idx / (nin + 1), c = idx - o * (nin + 1);
+    float sacc = 0.f;
+    if (c < nin) for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o] * in[p * ldi + c];
+    else for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
+    P[idx] += sacc;
+  }
+}
+
+__global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __restrict__ x,
+                                                      const float* __restrict__ cond, const float* __restrict__ gout,
+                                                      const float* __restrict__ gld, float* __restrict__ gx,
+                                                      float* __restrict__ gcond, float* __restrict__ part,
+                                                      float* __restrict__ part_mix) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TabLds L;
+  tab_layout(s, true, &L, smem);
+  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nout = tab_nout(s), nin0 = tab_nin0(s);
+  const int NP = tab_param_floats(s), NM = d * d + d;
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) L.PM[i] = 0.f;
+  const int ntiles = (s.B + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TR;
+    tab_forward_tile(s, L, x, cond, row0);
+    // ---- tail backward: grads wrt O (into GA) and wrt y2 (into GY second half)
+    for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
+      const int p = idx / C2, j = idx - p * C2, m = row0 + p;
+      const float g2 = m < s.B ? gout[(long)m * d + Ch + j] : 0.f;
+      const float gl = (m < s.B && gld) ? gld[m] : 0.f;
+      if (s.additive) {
+        L.GA[p * L.GS + j] = g2;
+        L.GY[p * L.XS + Ch + j] = g2;
+      } else {
+        const float shf = L.O[p * L.OS + 2 * j], sr = L.O[p * L.OS + 2 * j + 1];
+        const float sc = sigmoidf(sr + 2.f), z2 = L.Y[p * L.XS + Ch + j];
+        const float gshift = g2 * sc;
+        L.GA[p * L.GS + 2 * j] = gshift;
+        L.GA[p * L.GS + 2 * j + 1] = (m < s.B) ? g2 * (z2 + shf) * sc * (1.f - sc) + gl * (1.f - sc) : 0.f;
+        L.GY[p * L.XS + Ch + j] = gshift;
+      }
+    }
+    __syncthreads();
+    // ---- MLP backward (layers 5..0).  g = grad wrt the layer's PRE-activation output.
+    float* g = L.GA;
+    float* gn = L.GB;
+    for (int l = 5; l >= 0; --l) {
+      const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
+      const float* in = l == 0 ? L.IN0 : L.H[l - 1];
+      const int ldi = l == 0 ? L.IS : L.HS;
+      tab_wgrad(g, L.GS, in, ldi, nin, no, L.Pl + tab_param_off(s, l), TR);
+      // grad wrt this layer's input (post-activation of layer l-1)
+      tab_dense(g, L.GS, no, s.W[l], nullptr, gn, L.GS, nin, 0, 1, L.Wl, TR);
+      if (l > 0) {
+        const int act = (l - 1) == 4 ? 2 : 1;
+        for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
+          const int p = idx / nin, c = idx - p * nin;
+          const float h = L.H[l - 1][p * L.HS + c];
+          gn[p * L.GS + c] *= act == 1 ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
+        }
+        __syncthreads();
+      }
+      float* t = g; g = gn; gn = t;
+    }
+    // g = grad wrt IN0 = (z1 | cond)
+    for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+      const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+      if (c < Ch) L.GY[p * L.XS + c] = g[p * L.GS + c] + (m < s.B ? gout[(long)m * d + c] : 0.f);
+      else if (gcond && m < s.B) gcond[(long)m * s.ncond + (c - Ch)] += g[p * L.GS + c];
+    }
+    __syncthreads();
+    // ---- mix backward: gx = Wf^T gy ; partial (gWf, gcf)
+    for (int idx = threadIdx.x; idx < NM; idx += blockDim.x) {
+      float sacc = 0.f;
+      if (idx < d * d) {
+        const int o = idx / d, c = idx - o * d;
+        for (int p = 0; p < TR; ++p) sacc += L.GY[p * L.XS + o] * L.X[p * L.XS + c];
+      } else {
+        const int o = idx - d * d;
+        for (int p = 0; p < TR; ++p) sacc += L.GY[p * L.XS + o];
+      }
+      L.PM[idx] += sacc;
+    }
+    tab_dense(L.GY, L.XS, d, s.Wf, nullptr, gn, L.GS, d, 0, 1, L.Wl, TR);
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      if (m < s.B) gx[(long)m * d + c] = gn[p * L.GS + c];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) part[(long)blockIdx.x * NP + i] = L.Pl[i];
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) part_mix[(long)blockIdx.x * NM + i] = L.PM[i];
+}
+
+// gW[l][o][c] += sum_blk part[blk][off_l + o*(nin+1) + c];  gb[l][o] += ... [+ nin]
+__global__ void tab_reduce_kernel(TabStep s, nfk_tab_grads g, const float* __restrict__ part, int nblk) {
+  const int NP = tab_param_floats(s);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NP; i += gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[(long)b * NP + i];
+    int o = 0;
+    for (int l = 0; l < 6; ++l) {
+      const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l), n = no * (nin + 1);
+      if (i < o + n) {
+        const int r = (i - o) / (nin + 1), c = (i - o) - r * (nin + 1);
+        if (c < nin) g.gW[l][r * nin + c] += t; else g.gb[l][r] += t;
+        break;
+      }
+      o += n;
+    }
+  }
+}
+
+constexpr int TAB_MAX_BLOCKS = 128;
+
+static int tab_blocks(const TabStep& s, bool bwd) {
+  const int nt = ceil_div(s.B, tab_rows(s.hid, s.d));
+  const int cap = bwd ? TAB_MAX_BLOCKS : 2048;
+  return nt < cap ? nt : cap;
+}
+static int tab_check(const TabStep& s, bool bwd, size_t* lds) {
+  if (s.d < 2 || s.hid < 1 || s.B < 0 || s.ncond < 0) return NFK_ERR_ARG;
+  *lds = tab_layout(s, bwd, nullptr, nullptr);
+  return *lds > 160 * 1024 ? NFK_ERR_ARG : NFK_OK;
+}
+
+}  // namespace nfk
+
+using namespace nfk;
+extern "C" {
+
+int nfk_tab_bwd_blocks(const nfk_tab_step* s) { return tab_blocks(*s, true); }
+int nfk_tab_param_floats(const nfk_tab_step* s) { return tab_param_floats(*s); }
+
+int nfk_tab_fwd(const nfk_tab_step* s, const float* x, const float* cond, const float* ld_in, float* zout,
+                float* ld_out, void* stream) {
+  size_t lds;
+  if (tab_check(*s, false, &lds) != NFK_OK) return NFK_ERR_ARG;
+  if (s->B == 0) return NFK_OK;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  hipLaunchKernelGGL(tab_fwd_kernel, dim3(tab_blocks(*s, false)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                     *s, x, cond, ld_in, zout, ld_out);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_tab_inv(const nfk_tab_step* s, const float* y, const float* cond, const float* ld_in, float* xout,
+                float* ld_out, void* stream) {
+  size_t lds;
+  if (tab_check(*s, false, &lds) != NFK_OK || !s->Wi) return NFK_ERR_ARG;
+  if (s->B == 0) return NFK_OK;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  hipLaunchKernelGGL(tab_inv_kernel, dim3(tab_blocks(*s, false)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                     *s, y, cond, ld_in, xout, ld_out);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_tab_bwd(const nfk_tab_step* s, const nfk_tab_grads* g, const float* x, const float* cond,
+                const float* g_out, const float* g_ld, float* g_x, float* g_cond, float* part, float* part_mix,
+                void* stream) {
+  size_t lds;
+  if (tab_check(*s, true, &lds) != NFK_OK) return NFK_ERR_ARG;
+  if (s->B == 0) return NFK_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  const int nb = tab_blocks(*s, true);
+  hipLaunchKernelGGL(tab_bwd_kernel, dim3(nb), dim3(256), lds, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
+  NFK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tab_reduce_kernel, dim3(ceil_div(tab_param_floats(*s), 256)), dim3(256), 0, st, *s, *g, part, nb);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+}

@@ -369,6 +369,7 @@ class _EncodeFn(torch.autograd.Function):
         if eng.is_1d:
             cur = x.contiguous()
             for r in st["recs"]:
+                r.tab.part_mix = None
                 cur, ld, sv = r.tab.forward(cur, ld, y_onehot, need)
                 outs.append(cur)
                 saved.append(sv)
@@ -445,19 +446,43 @@ class _EncodeFn(torch.autograd.Function):
             g_ld = torch.zeros(B, device=dev, dtype=torch.float32)
         g_ld = g_ld.to(torch.float32).contiguous()
         n_in = 5 + len(eng.params())
-        if eng.is_1d:
-            g = None
-            for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):
-                if go is not None:
-                    g = go.contiguous() if g is None else g + go
-                g = r.tab.backward(sv, g, g_ld, ctx.y_onehot)
-            gx = g if ctx.needs_input_grad[1] else None
-            return (None, gx, g_ld if ctx.needs_input_grad[2] else None) + (None,) * (n_in - 3)
-
         # make sure every parameter has a grad buffer the kernels can accumulate into
         for p in eng.params():
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
+        if eng.is_1d:
+            g, g_y = None, None
+            want_gy = ctx.needs_input_grad[4]
+            for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):
+                if go is not None:
+                    g = go.to(torch.float32).contiguous() if g is None else g + go
+                if g is None:
+                    continue
+                g, gc = r.tab.backward(sv, g, g_ld, want_gy)
+                if gc is not None:
+                    g_y = gc if g_y is None else g_y + gc
+            pg = []
+            for r in recs:
+                d = PrepGrad()
+                if r.tab.part_mix is not None:
+                    d.part, d.nparts = r.tab.part_mix.data_ptr(), r.tab.nblk
+                    an, ic = r.mod.actnorm, r.mod.invconv
+                    d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
+                    if ic.LU_decomposed:
+                        d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
+                    else:
+                        d.g_weight = ptr(ic.weight.grad)
+                pg.append(d)
+            if all(d.nparts > 0 for d in pg):
+                grad_dev = capi.struct_array_to_device(pg, dev)
+                check(lib.nfk_prep_bwd(ptr(st["prep_dev"]), ptr(grad_dev), st["n_prep"], ptr(g_ld), B, st["any_dense"], s),
+                      "nfk_prep_bwd")
+                ctx.keep = (grad_dev,)
+            elif any(d.nparts > 0 for d in pg):
+                raise RuntimeError("partial backward through a 1-D flow is not supported")
+            gx = g if ctx.needs_input_grad[1] else None
+            return (None, gx, g_ld if ctx.needs_input_grad[2] else None, None, g_y) + (None,) * (n_in - 5)
+
         scratch = _Scratch(st, dev)
         # per-step partial (gWf, gcf) arena for nfk_prep_bwd
         part_off, total = {}, 0

@@ -1,0 +1,77 @@
+"""Host side of the 1-D (tabular) FlowStep: binds one `nfk_tab_step` per layer.
+
+Reference: FlowStep with is_1d (models/flows.py:142-202), get_block_1d (models/flows.py:37-52),
+ActNorm1d / InvertibleConv1x1 1-D branch (models/layers.py:159-170, 410-411)."""
+import ctypes as C
+
+import torch
+
+from . import capi
+from .capi import TabGrads, TabStepC, check, ptr
+
+_LIN = (0, 2, 4, 6, 8, 10)
+
+
+class TabStep:
+    def __init__(self, rec, B, prep_base, off):
+        layer = rec.mod
+        self.layer, self.rec, self.B = layer, rec, B
+        s = TabStepC()
+        s.B, s.d, s.hid, s.ncond = B, rec.C, rec.hid, layer.condition_features
+        s.additive = rec.additive
+        for k, li in enumerate(_LIN):
+            lin = layer.block[li]
+            for t in (lin.weight, lin.bias):
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError("nfk tab kernels need contiguous fp32 parameters")
+            s.W[k], s.b[k] = ptr(lin.weight), ptr(lin.bias)
+        for nm in ("Wf", "cf", "Wi", "ci", "dld"):
+            setattr(s, nm, prep_base + 4 * off[nm])
+        self.cs = s
+        lib = capi.lib()
+        self.nblk = lib.nfk_tab_bwd_blocks(C.byref(s))
+        self.nparam = lib.nfk_tab_param_floats(C.byref(s))
+        self.part_mix = None
+
+    def _cond(self, y_onehot, forward):
+        # forward conditions on "y given", reverse on "model has condition features" (models/flows.py:152 vs :177)
+        use = (y_onehot is not None) if forward else bool(self.cs.ncond)
+        if use:
+            if y_onehot is None or y_onehot.shape[1] != self.cs.ncond:
+                raise RuntimeError(f"FlowStep expects {self.cs.ncond} condition features")
+            return y_onehot.to(torch.float32).contiguous()
+        if self.cs.ncond:
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (conditional block called without y_onehot)")
+        return None
+
+    def forward(self, x, ld, y_onehot, need):
+        lib, s = capi.lib(), capi.stream()
+        cond = self._cond(y_onehot, True)
+        out = torch.empty_like(x)
+        ld_out = torch.empty_like(ld)
+        check(lib.nfk_tab_fwd(C.byref(self.cs), ptr(x), ptr(cond), ptr(ld), ptr(out), ptr(ld_out), s), "nfk_tab_fwd")
+        return out, ld_out, ((x, cond) if need else None)
+
+    def inverse(self, y, y_onehot):
+        lib, s = capi.lib(), capi.stream()
+        cond = self._cond(y_onehot, False)
+        out = torch.empty_like(y)
+        check(lib.nfk_tab_inv(C.byref(self.cs), ptr(y), ptr(cond), None, ptr(out), None, s), "nfk_tab_inv")
+        return out
+
+    def backward(self, saved, g_out, g_ld, want_gcond):
+        lib, s = capi.lib(), capi.stream()
+        x, cond = saved
+        blk = self.layer.block
+        g = TabGrads()
+        for k, li in enumerate(_LIN):
+            g.gW[k], g.gb[k] = ptr(blk[li].weight.grad), ptr(blk[li].bias.grad)
+        d = self.cs.d
+        part = torch.empty(self.nblk * self.nparam, device=x.device, dtype=torch.float32)
+        self.part_mix = torch.empty(self.nblk * (d * d + d), device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(x)
+        gcond = torch.zeros_like(cond) if (cond is not None and want_gcond) else None
+        check(lib.nfk_tab_bwd(C.byref(self.cs), C.byref(g), ptr(x), ptr(cond), ptr(g_out), ptr(g_ld), ptr(gx), ptr(gcond),
+                              ptr(part), ptr(self.part_mix), s), "nfk_tab_bwd")
+        self._keep = part
+        return gx, gcond

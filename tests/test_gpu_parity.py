@@ -129,3 +129,52 @@ def test_logdet_is_deterministic():
             _, bpd, _ = model(g.t("x").cuda(), None, noise=g.t("noise").cuda())
         res.append(bpd.cpu())
     assert torch.equal(res[0], res[1]) and torch.equal(res[1], res[2])
+
+
+CASES_1D = ["tab6", "tab63", "tab6_k5_h32", "tab5_cond"]
+
+
+@pytest.mark.parametrize("name", CASES_1D)
+def test_tabular_forward_backward_reverse(name):
+    """1-D Glow (BASELINE.json configs 1 and 5 map onto this path: SURVEY.md §0 F1)."""
+    g = Golden(name)
+    model = build(g.cfg, g.group("sd"))
+    x = g.t("x").cuda()
+    y = g.t("y").cuda() if g.has("y") else None
+    outs, nll, y_logits = model(x, y)
+    for i, (o, r) in enumerate(zip(outs, g.seq("out"))):
+        assert rel_err(o.cpu(), r) < 2e-5, (i, rel_err(o.cpu(), r))
+    assert rel_err(nll.cpu(), g.t("bpd")) < 1e-5
+    loss = nll.mean()
+    if y_logits is not None:
+        assert rel_err(y_logits.cpu(), g.t("y_logits")) < 2e-5
+        loss = loss + 0.1 * (y_logits ** 2).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        ref = g.t(f"grad/{k}")
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert float(got.abs().max()) < 1e-6, k
+        else:
+            assert rel_err(got, ref) < 1e-3, (k, rel_err(got, ref))
+    with torch.no_grad():
+        rev = model(z=outs[-1].detach(), y_onehot=y, temperature=0.0, reverse=True)
+    for i, (o, r) in enumerate(zip(rev, g.seq("rev"))):
+        assert rel_err(o.cpu(), r) < 1e-4, (i, rel_err(o.cpu(), r))
+    # exact inverse: the last reverse output reproduces the input rows
+    assert rel_err(rev[-1].cpu(), g.t("x")) < 1e-4
+
+
+def test_tabular_large_batch_round_trip():
+    """POWER-shaped batch of 65 536 rows (conf/training/tabular.yaml:7): encode -> decode."""
+    g = Golden("tab6_k5_h32")
+    model = build(g.cfg, g.group("sd"))
+    torch.manual_seed(0)
+    x = torch.randn(65536, 6, device="cuda")
+    with torch.no_grad():
+        outs, nll, _ = model(x.clone(), None)
+        rev = model(z=outs[-1], temperature=1.0, reverse=True)
+    assert rel_err(rev[-1].cpu(), x.cpu()) < 1e-4
+    assert torch.isfinite(nll).all()
