@@ -54,6 +54,12 @@ def cpu_baseline(batch, steps):
     from oracle import glow_oracle as O
     from param_util import randomize_state_dict, synthetic_images
     from test_oracle_golden import full_shapes
+    # a 1-GPU box gets a 16-CPU share of the host; more threads than that only thrash
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))
     s_cfg, t_cfg = cifar_cfg(8), cifar_cfg(32)
     s_sd = randomize_state_dict(full_shapes(s_cfg), 11)
     t_sd = randomize_state_dict(full_shapes(t_cfg), 12)

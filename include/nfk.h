@@ -206,6 +206,8 @@ int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const 
 enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW = 2, NFK_PROF_WGRAD_WIDE = 3,
        NFK_PROF_WGRAD_NARROW = 4, NFK_PROF_CLASSES = 5 };
 void nfk_profile_begin(void);
+/* experiment knob for tools/gemm_bench.py: selects an alternative tile configuration (0 = default) */
+void nfk_set_tuning(int v);
 void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
 
 const char *nfk_version(void);

@@ -80,6 +80,7 @@ i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long
 _PROTOS = {
     "nfk_version": (C.c_char_p, []),
     "nfk_profile_begin": (None, []),
+    "nfk_set_tuning": (None, [i32]),
     "nfk_profile_end": (None, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
     "nfk_padded_k": (i32, [i32]),

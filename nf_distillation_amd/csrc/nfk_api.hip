@@ -56,6 +56,7 @@ ConvGemmArgs conv_args(const float* X, int ldx, int B, int H, int W, int Cin, in
 
 extern "C" {
 
+void nfk_set_tuning(int v) { set_tuning(v); }
 void nfk_profile_begin(void) { prof_begin(); }
 void nfk_profile_end(double* ms, long long* launches, double* flops, double* bytes) {
   prof_end(ms, launches, flops, bytes);

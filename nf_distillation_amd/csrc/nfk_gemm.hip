@@ -24,25 +24,46 @@ constexpr int LS = BK + 4;   // LDS row stride (floats): 144 B keeps ds_read_b12
 
 
 
+// Buffer-resource loads (hardware bounds check: offset >= num_records reads as 0).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+
 // XCD-aware block remap (bijective): blocks that share an XCD (id % 8) get a contiguous range.
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
-template <int TN, int TM>
+// LDS tile addressing.  SWZ=false: rows padded to 36 floats (2-way conflicts on ds_read_b128).
+// SWZ=true: 32-float rows, 16-byte slot index XORed with (row>>1)&7 -- conflict-free for the
+// ds_read_b128 lane groups of gfx950 and 11 % less LDS.  Tile row bases are multiples of 16.
+template <bool SWZ>
+__device__ __forceinline__ int lds_off(int row, int slot) {
+  return SWZ ? row * BK + ((slot ^ ((row >> 1) & 7)) << 2) : row * LS + (slot << 2);
+}
+
+template <int TN, int TM, bool SWZ>
 __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, const float* __restrict__ Bs,
                                                int arow0, int brow0, int lane, f32x4 (&acc)[TN][TM]) {
-  const int r = lane & 15, kq = (lane >> 4) * 4;
+  const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int kh = 0; kh < 2; ++kh) {
     f32x4 a[TN], b[TM];
 #pragma unroll
     for (int t = 0; t < TN; ++t)
-      a[t] = *reinterpret_cast<const f32x4*>(As + (arow0 + t * 16 + r) * LS + kh * 16 + kq);
+      a[t] = *reinterpret_cast<const f32x4*>(As + lds_off<SWZ>(arow0 + t * 16 + r, kh * 4 + q));
 #pragma unroll
     for (int t = 0; t < TM; ++t)
-      b[t] = *reinterpret_cast<const f32x4*>(Bs + (brow0 + t * 16 + r) * LS + kh * 16 + kq);
+      b[t] = *reinterpret_cast<const f32x4*>(Bs + lds_off<SWZ>(brow0 + t * 16 + r, kh * 4 + q));
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -83,10 +104,11 @@ __device__ __forceinline__ void mfma_tile_step_kmajor(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // conv / dgrad kernel
 // ------------------------------------------------------------------------------------------
-template <int TN, int TM, int WN, int WM>
+template <int TN, int TM, int WN, int WM, bool SWZ>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvGemmArgs a) {
   static_assert(WN * WM == 4, "256-thread workgroups");
   constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
+  constexpr int LSK = SWZ ? BK : LS;
   constexpr int WL = (BN * 8 + 255) / 256, XL = BM / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -101,76 +123,91 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvGemmArgs a) {
   const int S = gridDim.y, z = blockIdx.y;
   const int c_begin = (int)((long)a.nkchunks * z / S), c_end = (int)((long)a.nkchunks * (z + 1) / S);
 
-  // fixed per-thread load coordinates
+  // Operands are fetched with buffer loads: an offset >= num_records returns 0, so SAME zero padding,
+  // the k tail and the row/column tails of the last tiles need no branches (one v_cndmask per load).
+  const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, (unsigned)((long)a.M * a.ldx * 4));
+  const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.Wt, (unsigned)((long)a.N * a.Kp * 4));
   const int lq = tid & 7, lr = tid >> 3;
-  int pix[XL], yx[XL];
+  unsigned rowoff[XL], woff[WL];
+  int yx[XL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
     const int m = m0 + lr + 32 * i;
-    if (m < a.M) {
-      const int rem = m % HW;
-      pix[i] = m;
-      yx[i] = ((rem / a.W) << 16) | (rem % a.W);
-    } else {
-      pix[i] = -1;
-      yx[i] = 0;
-    }
+    const int rem = m % HW;
+    rowoff[i] = m < a.M ? (unsigned)m * (unsigned)a.ldx * 4u : BUF_OOB;
+    yx[i] = ((rem / a.W) << 16) | (rem % a.W);
   }
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    const int r = (tid + 256 * i) >> 3, n = n0 + r;
+    woff[i] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.Kp * 4u : BUF_OOB;
+  }
+  const bool unif = vec && (a.Cin % BK) == 0;  // a k-chunk never straddles a tap: tap is wave-uniform
 
   f32x4 wreg[WL], xreg[XL];
+  auto tap_shift = [&](int tap, int& dy, int& dx) {
+    dy = (a.taps == 1) ? 0 : tap / 3 - 1;
+    dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+  };
   auto gload = [&](int chunk) {
     const int k = chunk * BK + lq * 4;
 #pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const int idx = tid + 256 * i, r = idx >> 3;
-      const int n = n0 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < BN && n < a.N) v = *reinterpret_cast<const f32x4*>(a.Wt + (long)n * a.Kp + k);
-      wreg[i] = v;
-    }
-    if (vec) {
+    for (int i = 0; i < WL; ++i) wreg[i] = buf_load4(rW, woff[i] + (unsigned)k * 4u);
+    if (unif) {
+      const int kb = chunk * BK;
+      const int tap = (a.taps == 1) ? 0 : kb / a.Cin;
+      int dy, dx;
+      tap_shift(tap, dy, dx);
+      const unsigned add = (unsigned)((dy * a.W + dx) * a.ldx + (kb - tap * a.Cin) + lq * 4) * 4u;
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
+        const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        xreg[i] = buf_load4(rX, ok ? rowoff[i] + add : BUF_OOB);
+      }
+    } else if (vec) {
       int tap = 0, ci = k;
       if (a.taps != 1) { tap = k / a.Cin; ci = k - tap * a.Cin; }
-      const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+      int dy, dx;
+      tap_shift(tap, dy, dx);
+      const unsigned add = (unsigned)((dy * a.W + dx) * a.ldx + ci) * 4u;
       const bool kok = k < a.K;
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
         const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kok && pix[i] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
-          v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix[i] + dy * a.W + dx) * a.ldx + ci);
-        xreg[i] = v;
+        const bool ok = kok && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        xreg[i] = buf_load4(rX, ok ? rowoff[i] + add : BUF_OOB);
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < XL; ++i) xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kk = k + j;
         int tap = 0, ci = kk;
         if (a.taps != 1) { tap = kk / a.Cin; ci = kk - tap * a.Cin; }
-        const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+        int dy, dx;
+        tap_shift(tap, dy, dx);
+        const unsigned add = (unsigned)((dy * a.W + dx) * a.ldx + ci) * 4u;
         const bool kok = kk < a.K;
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
           const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
-          if (kok && pix[i] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
-            xreg[i][j] = a.X[(long)(pix[i] + dy * a.W + dx) * a.ldx + ci];
+          const bool ok = kok && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+          xreg[i][j] = buf_load1(rX, ok ? rowoff[i] + add : BUF_OOB);
         }
       }
     }
   };
   auto lstore = [&](int buf) {
-    float* Ws = smem + buf * (BN + BM) * LS;
-    float* Xs = Ws + BN * LS;
+    float* Ws = smem + buf * (BN + BM) * LSK;
+    float* Xs = Ws + BN * LSK;
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3;
-      if (r < BN) *reinterpret_cast<f32x4*>(Ws + r * LS + lq * 4) = wreg[i];
+      if (r < BN) *reinterpret_cast<f32x4*>(Ws + lds_off<SWZ>(r, lq)) = wreg[i];
     }
 #pragma unroll
     for (int i = 0; i < XL; ++i)
-      *reinterpret_cast<f32x4*>(Xs + (lr + 32 * i) * LS + lq * 4) = xreg[i];
+      *reinterpret_cast<f32x4*>(Xs + lds_off<SWZ>(lr + 32 * i, lq)) = xreg[i];
   };
 
   f32x4 acc[TN][TM];
@@ -187,8 +224,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvGemmArgs a) {
   for (int c = c_begin; c < c_end; ++c) {
     const int buf = (c - c_begin) & 1;
     if (c + 1 < c_end) gload(c + 1);
-    const float* Ws = smem + buf * (BN + BM) * LS;
-    mfma_tile_step<TN, TM>(Ws, Ws + BN * LS, wn * 16 * TN, wm * 16 * TM, lane, acc);
+    const float* Ws = smem + buf * (BN + BM) * LSK;
+    mfma_tile_step<TN, TM, SWZ>(Ws, Ws + BN * LSK, wn * 16 * TN, wm * 16 * TM, lane, acc);
     if (c + 1 < c_end) lstore(buf ^ 1);
     __syncthreads();
   }
@@ -521,21 +558,21 @@ void prof_end(double* ms, long long* launches, double* flops, double* bytes) {
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
-template <int TN, int TM, int WN, int WM>
+template <int TN, int TM, int WN, int WM, bool SWZ = true>
 static int launch_conv(const ConvGemmArgs& a, int S, hipStream_t st, int cls) {
   constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
-  constexpr size_t lds = 2 * (BN + BM) * LS * sizeof(float);
+  constexpr size_t lds = 2 * (BN + BM) * (SWZ ? BK : LS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TN, TM, WN, WM>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TN, TM, WN, WM, SWZ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(ceil_div(a.N, BN) * ceil_div(a.M, BM), S);
   ProfScope ps(cls, 2.0 * a.M * (double)a.N * a.K,
                4.0 * ((double)a.M * a.Cin + (double)a.N * a.K + (double)S * a.M * a.N), st);
-  hipLaunchKernelGGL((conv_gemm_kernel<TN, TM, WN, WM>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<TN, TM, WN, WM, SWZ>), grid, dim3(256), lds, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
@@ -580,6 +617,9 @@ int conv_mblocks(int M, int N) {
   return ceil_div(M, 128);
 }
 
+static int g_tune = 0;
+void set_tuning(int v) { g_tune = v; }
+
 int conv_gemm(ConvGemmArgs a, hipStream_t st) {
   if (a.taps != 1 && a.taps != 9) return NFK_ERR_ARG;
   a.K = a.taps * a.Cin;
@@ -587,9 +627,15 @@ int conv_gemm(ConvGemmArgs a, hipStream_t st) {
   a.nkchunks = ceil_div(a.K, BK);
   if (a.Kp < a.nkchunks * BK) return NFK_ERR_ARG;
   if (a.M <= 0 || a.N <= 0) return NFK_OK;
+  if ((long)a.M * a.ldx * 4 >= 0x7fffffffL || (long)a.N * a.Kp * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
   const int S = conv_splitk(a.M, a.N, a.K, a.epi);
   if (a.N > 96) {
     const bool big = (long)ceil_div(a.N, 128) * ceil_div(a.M, 128) >= 256;
+    if (g_tune == 1) return launch_conv<4, 4, 2, 2, false>(a, S, st, NFK_PROF_CONV_WIDE128);
+    if (g_tune == 2) return launch_conv<4, 2, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128);
+    if (g_tune == 3) return launch_conv<2, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128);
+    if (g_tune == 4) return launch_conv<2, 2, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE64);
+    if (g_tune == 5) return launch_conv<4, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128);
     return big ? launch_conv<4, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128) : launch_conv<2, 2, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE64);
   }
   switch (ceil_div(a.N, 16)) {

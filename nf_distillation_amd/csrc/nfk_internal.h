@@ -104,6 +104,7 @@ struct PriorBwdArgs {
   int HW, C; float bpd_scale;
 };
 
+void set_tuning(int v);
 void prof_begin();
 void prof_end(double* ms, long long* launches, double* flops, double* bytes);
 int padded_k(int K);
