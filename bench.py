@@ -30,6 +30,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 
 
 def cifar_cfg(K):
@@ -85,6 +86,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "
+                         "coupling-net convs (BASELINE.json config 2; bits/dim within 0.01: tests/test_gpu_bf16.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +109,8 @@ def main():
     from param_util import synthetic_images
 
     student, teacher = make_models(device)
+    student.set_compute_dtype(args.dtype)
+    teacher.set_compute_dtype(args.dtype)
     step = DistillationStep(student, teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
 
     # synthetic data, resident in HBM before the timed region; a few distinct batches, cycled
@@ -136,7 +142,7 @@ def main():
         "metric": "train images/sec Glow CIFAR-10 distillation step",
         "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "Glow CIFAR-10 32x32 distillation training_step: teacher L=3 K=32 h=512 fwd (no grad) + "
                                "student L=3 K=8 h=512 fwd+bwd + MSE hints + clip 30 + Adam",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
@@ -150,9 +156,11 @@ def main():
         dom = max(prof, key=lambda d: d["ms"])
         avg_ms = dom["ms"] / max(dom["launches"], 1)
         achieved = dom["flops"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12
+        peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
         result["roofline"] = {
-            "bound": "mfma", "kernel": dom["kernel"], "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "bound": "mfma", "kernel": dom["kernel"] + (" [bf16]" if args.dtype == "bf16" else ""),
+            "achieved": achieved, "peak": peak,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
             "launches_per_step": dom["launches"] / args.steps, "avg_launch_us": 1e3 * avg_ms,
             "algorithmic_gflop_per_launch": dom["flops"] / max(dom["launches"], 1) / 1e9,
             "gemm_ms_per_step": {d["kernel"]: d["ms"] / args.steps for d in prof},

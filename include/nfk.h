@@ -60,7 +60,8 @@ typedef struct nfk_prep_grad {
 /* One 2-D FlowStep (models/flows.py:55-202) with a 3-conv coupling net (models/flows.py:25-34). */
 typedef struct nfk_step2d {
   int32_t B, H, W, C, hidden, Cout; /* Cout = C - C/2 (additive) or 2*(C - C/2) (affine) */
-  int32_t additive, pad_;
+  int32_t additive;
+  int32_t bf16;                     /* 1: h1/h2 (and their grads) are bf16 in HBM; wt and wd are bf16 [N][Kp64] */
   const float *b1, *b2, *bias3;     /* block.0/.2 actnorm.bias [hidden], block.4 conv.bias [Cout] */
   const float *Wf, *cf, *Wi, *ci, *dld, *es1, *es2, *es3; /* from nfk_prep */
   const float *wt1, *wt2, *wt3;     /* repacked forward weights [N][Kp]  (nfk_repack) */
@@ -126,6 +127,9 @@ int nfk_prep_bwd(const nfk_prep_desc *descs, const nfk_prep_grad *grads, int nst
 int nfk_repack(const float *w, int Cout, int Cin, int taps, float *wt, float *wd, void *stream);
 /* all conv weights of a model in one launch; descs: DEVICE array[n] */
 int nfk_repack_batch(const nfk_repack_desc *descs, int n, void *stream);
+/* same, to bf16 with k padded to 64 (throughput mode: nfk_step2d.bf16 = 1) */
+int nfk_repack_batch_bf16(const nfk_repack_desc *descs, int n, void *stream);
+int nfk_padded_k_bf16(int K);
 
 /* ---- op-level entry points (unit-testable primitives) -------------------------------------- */
 /* z[m][:] = Wm x[m][:] + cv   -- _ActNorm.forward + InvertibleConv1x1.forward / Permute2d

@@ -42,7 +42,7 @@ class PrepGrad(C.Structure):
 
 class Step2d(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-                ("hidden", C.c_int32), ("Cout", C.c_int32), ("additive", C.c_int32), ("pad_", C.c_int32),
+                ("hidden", C.c_int32), ("Cout", C.c_int32), ("additive", C.c_int32), ("bf16", C.c_int32),
                 ("b1", c_fp), ("b2", c_fp), ("bias3", c_fp),
                 ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp),
                 ("es1", c_fp), ("es2", c_fp), ("es3", c_fp),
@@ -94,6 +94,8 @@ _PROTOS = {
     "nfk_prep_bwd": (i32, [vp, vp, i32, vp, i32, i32, vp]),
     "nfk_repack": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "nfk_repack_batch": (i32, [vp, i32, vp]),
+    "nfk_repack_batch_bf16": (i32, [vp, i32, vp]),
+    "nfk_padded_k_bf16": (i32, [i32]),
     "nfk_chanmix": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp]),
     "nfk_conv": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
     "nfk_coupling_fwd": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

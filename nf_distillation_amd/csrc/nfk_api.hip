@@ -7,6 +7,7 @@ using namespace nfk;
 namespace {
 inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align4(size_t n) { return (n + 3) & ~size_t(3); }
+int splitk_of(int bf16, int M, int N, int K);
 #define NFK_TRY(expr)            \
   do {                           \
     const int rc_ = (expr);      \
@@ -21,11 +22,11 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   StepBwdWs w;
   const size_t M = (size_t)s->B * s->H * s->W;
   const int Ch = s->C / 2, hid = s->hidden;
-  w.S1 = conv_splitk((int)M, Ch, 9 * hid, EPI_RAW);
+  w.S1 = splitk_of(s->bf16, (int)M, Ch, 9 * hid);
   w.S3w = wgrad_splits((int)M, s->Cout, 9 * hid);
   w.S2w = wgrad_splits((int)M, hid, hid);
   w.S1w = wgrad_splits((int)M, hid, 9 * Ch);
-  w.mb = conv_mblocks((int)M, hid);
+  w.mb = s->bf16 ? conv_mblocks_bf16((int)M, hid) : conv_mblocks((int)M, hid);
   size_t o = 0;
   w.ga3 = o; o += align4(M * s->Cout);
   w.gz = o; o += align4(M * s->C);
@@ -45,12 +46,17 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
 }
 
 ConvGemmArgs conv_args(const float* X, int ldx, int B, int H, int W, int Cin, int taps, const float* Wt, int N,
-                       float* out, int ldo, int epi) {
+                       float* out, int ldo, int epi, int bf16 = 0, int xf32 = 1, int obf16 = 0) {
   ConvGemmArgs a{};
   a.X = X; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.taps = taps;
-  a.Wt = Wt; a.Kp = padded_k(taps * Cin); a.N = N;
+  a.Wt = Wt; a.Kp = bf16 ? padded_k_bf16(taps * Cin) : padded_k(taps * Cin); a.N = N;
   a.out = out; a.ldo = ldo; a.slab_stride = (long)B * H * W * ldo; a.epi = epi;
+  a.xf32 = xf32; a.obf16 = obf16;
   return a;
+}
+inline int run_conv(int bf16, const ConvGemmArgs& a, hipStream_t st) { return bf16 ? conv_gemm_bf16(a, st) : conv_gemm(a, st); }
+int splitk_of(int bf16, int M, int N, int K) {
+  return bf16 ? conv_splitk_bf16(M, N, K, EPI_RAW) : conv_splitk(M, N, K, EPI_RAW);
 }
 }  // namespace
 
@@ -70,7 +76,7 @@ int nfk_chanmix_blocks(int M, int C) { return chanmix_parts(M, C); }
 
 size_t nfk_step2d_fwd_ws_floats(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;
-  return align4((size_t)conv_splitk((int)M, s->Cout, 9 * s->hidden, EPI_RAW) * M * s->Cout);
+  return align4((size_t)splitk_of(s->bf16, (int)M, s->Cout, 9 * s->hidden) * M * s->Cout);
 }
 size_t nfk_step2d_bwd_ws_floats(const nfk_step2d* s) { return step_bwd_layout(s).total; }
 size_t nfk_split2d_fwd_ws_floats(const nfk_split2d* s) {
@@ -97,6 +103,10 @@ int nfk_repack(const float* w, int Cout, int Cin, int taps, float* wt, float* wd
 }
 
 int nfk_repack_batch(const nfk_repack_desc* descs, int n, void* stream) { return repack_batch(descs, n, S_(stream)); }
+int nfk_repack_batch_bf16(const nfk_repack_desc* descs, int n, void* stream) {
+  return repack_batch_bf16(descs, n, S_(stream));
+}
+int nfk_padded_k_bf16(int K) { return padded_k_bf16(K); }
 
 int nfk_chanmix(const float* x, int ldx, const float* Wm, const float* cv, float* z, int ldz, int M, int C,
                 void* stream) {
@@ -165,14 +175,15 @@ int nfk_prior_bwd(const float* z, int ldz, const float* prior, long prior_bstrid
 static int coupling_net_fwd(const nfk_step2d* s, const float* zin, int ldz, float* h1, float* h2, float* ws,
                             hipStream_t st) {
   const int Ch = s->C / 2, hid = s->hidden;
-  ConvGemmArgs c1 = conv_args(zin, ldz, s->B, s->H, s->W, Ch, 9, s->wt1, hid, h1, hid, EPI_AN_RELU);
+  const int bf = s->bf16;  // bf16 mode: h1/h2 are bf16 in HBM, weights bf16, z stays fp32
+  ConvGemmArgs c1 = conv_args(zin, ldz, s->B, s->H, s->W, Ch, 9, s->wt1, hid, h1, hid, EPI_AN_RELU, bf, 1, bf);
   c1.e0 = s->b1; c1.e1 = s->es1;
-  NFK_TRY(conv_gemm(c1, st));
-  ConvGemmArgs c2 = conv_args(h1, hid, s->B, s->H, s->W, hid, 1, s->wt2, hid, h2, hid, EPI_AN_RELU);
+  NFK_TRY(run_conv(bf, c1, st));
+  ConvGemmArgs c2 = conv_args(h1, hid, s->B, s->H, s->W, hid, 1, s->wt2, hid, h2, hid, EPI_AN_RELU, bf, !bf, bf);
   c2.e0 = s->b2; c2.e1 = s->es2;
-  NFK_TRY(conv_gemm(c2, st));
-  ConvGemmArgs c3 = conv_args(h2, hid, s->B, s->H, s->W, hid, 9, s->wt3, s->Cout, ws, s->Cout, EPI_RAW);
-  return conv_gemm(c3, st);
+  NFK_TRY(run_conv(bf, c2, st));
+  ConvGemmArgs c3 = conv_args(h2, hid, s->B, s->H, s->W, hid, 9, s->wt3, s->Cout, ws, s->Cout, EPI_RAW, bf, !bf, 0);
+  return run_conv(bf, c3, st);
 }
 
 int nfk_step2d_fwd(const nfk_step2d* s, const float* x, int ldx, const float* ld_in, float* z, float* h1,
@@ -184,7 +195,7 @@ int nfk_step2d_fwd(const nfk_step2d* s, const float* x, int ldx, const float* ld
   m.x = x; m.ldx = ldx; m.Wm = s->Wf; m.cv = s->cf; m.z = z; m.ldz = s->C; m.M = M; m.C = s->C;
   NFK_TRY(launch_chanmix(m, st));
   NFK_TRY(coupling_net_fwd(s, z, s->C, h1, h2, ws, st));
-  const int S = conv_splitk(M, s->Cout, 9 * s->hidden, EPI_RAW);
+  const int S = splitk_of(s->bf16, M, s->Cout, 9 * s->hidden);
   return nfk_coupling_fwd(ws, S, s->bias3, s->es3, z, s->C, zout, s->C, hsave, ld_in, s->dld, ld_out, s->B, HW,
                           s->C, s->Cout, s->additive, stream);
 }
@@ -195,7 +206,7 @@ int nfk_step2d_inv(const nfk_step2d* s, const float* y, int ldy, const float* ld
   const int M = s->B * s->H * s->W, HW = s->H * s->W;
   if (!s->Wi || !s->ci) return NFK_ERR_ARG;
   NFK_TRY(coupling_net_fwd(s, y, ldy, h1, h2, ws, st));
-  const int S = conv_splitk(M, s->Cout, 9 * s->hidden, EPI_RAW);
+  const int S = splitk_of(s->bf16, M, s->Cout, 9 * s->hidden);
   NFK_TRY(nfk_coupling_inv(ws, S, s->bias3, s->es3, y, ldy, z, s->C, ld_in, s->dld, ld_out, s->B, HW, s->C,
                            s->Cout, s->additive, stream));
   ChanMixArgs m{};
@@ -208,7 +219,7 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
                    const float* g_ld, float* g_x, float* ws, void* stream) {
   hipStream_t st = S_(stream);
   const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, hid = s->hidden, Cout = s->Cout;
-  const int M = B * H * W, HW = H * W;
+  const int M = B * H * W, HW = H * W, bf = s->bf16;
   const StepBwdWs L = step_bwd_layout(s);
   float *ga3 = ws + L.ga3, *gz = ws + L.gz, *ga2 = ws + L.ga2, *ga1 = ws + L.ga1, *d1 = ws + L.d1slab;
   float *col2 = ws + L.col2, *col1 = ws + L.col1, *tail = ws + L.tail, *wslab = ws + L.wslab;
@@ -223,30 +234,33 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   WgradArgs w3{};
   w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
   w3.B = B; w3.H = H; w3.W = W; w3.out = wslab; w3.slab_stride = (long)Cout * 9 * hid;
+  w3.qbf16 = bf;
   NFK_TRY(wgrad_gemm(w3, L.S3w, st));
   NFK_TRY(wgrad_finalize(wslab, L.S3w, w3.slab_stride, Cout, hid, 9, g->g_w3, st));
-  ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD);
+  ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD, bf, 1, bf);
   d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
-  NFK_TRY(conv_gemm(d3, st));
+  NFK_TRY(run_conv(bf, d3, st));
 
   // conv2 (block.2)
   WgradArgs w2{};
   w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
   w2.B = B; w2.H = H; w2.W = W; w2.out = wslab; w2.slab_stride = (long)hid * hid;
+  w2.pbf16 = bf; w2.qbf16 = bf;
   NFK_TRY(wgrad_gemm(w2, L.S2w, st));
   NFK_TRY(wgrad_finalize(wslab, L.S2w, w2.slab_stride, hid, hid, 1, g->g_w2, st));
-  ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD);
+  ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
   d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
-  NFK_TRY(conv_gemm(d2, st));
+  NFK_TRY(run_conv(bf, d2, st));
 
   // conv1 (block.0)
   WgradArgs w1{};
   w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = z; w1.ldq = C; w1.Cq = Ch; w1.taps = 9;
   w1.B = B; w1.H = H; w1.W = W; w1.out = wslab; w1.slab_stride = (long)hid * 9 * Ch;
+  w1.pbf16 = bf;
   NFK_TRY(wgrad_gemm(w1, L.S1w, st));
   NFK_TRY(wgrad_finalize(wslab, L.S1w, w1.slab_stride, hid, Ch, 9, g->g_w1, st));
-  ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW);
-  NFK_TRY(conv_gemm(d1a, st));
+  ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
+  NFK_TRY(run_conv(bf, d1a, st));
 
   nfk_small_grad_args sg{};
   sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb; sg.mb2 = L.mb; sg.B = B;

@@ -26,6 +26,7 @@ constexpr int LS = BK + 4;   // LDS row stride (floats): 144 B keeps ds_read_b12
 
 // Buffer-resource loads (hardware bounds check: offset >= num_records reads as 0).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned BUF_OOB = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -333,54 +334,83 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   const int c_begin = (int)((long)nchunks * z / S), c_end = (int)((long)nchunks * (z + 1) / S);
   const bool pvec = ((a.NI | a.ldp) & 3) == 0, qvec = ((a.Cq | a.ldq) & 3) == 0;
 
-  // thread -> (pixel within chunk, channel group of 4): channel groups fastest => coalesced rows
+  // thread -> (pixel within chunk, channel group of 4): channel groups fastest => coalesced rows.
+  // Sources are read with buffer loads (bounds check = zero fill); bf16 sources are widened to f32 here.
   constexpr int PG = BI / 4, QG = BJ / 4;
+  const unsigned pes = a.pbf16 ? 2u : 4u, qes = a.qbf16 ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rP = make_rsrc(a.P, (unsigned)((long)a.M * a.ldp * pes));
+  const __amdgpu_buffer_rsrc_t rQ = make_rsrc(a.Q, (unsigned)((long)a.M * a.ldq * qes));
+  auto load4 = [&](__amdgpu_buffer_rsrc_t r, unsigned off, bool isbf) {
+    if (isbf) {
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+      return f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+    }
+    return buf_load4(r, off);
+  };
+  auto load1 = [&](__amdgpu_buffer_rsrc_t r, unsigned off, bool isbf) {
+    if (isbf) {
+      const unsigned h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0);
+      return __builtin_bit_cast(float, h << 16);
+    }
+    return buf_load1(r, off);
+  };
+  // per-thread constants: P column group, Q (tap, channel) of each slot
+  int p_pl[PL], q_pl[QL], q_dyx[QL][4];
+  unsigned p_col[PL], q_col[QL][4];
+#pragma unroll
+  for (int t = 0; t < PL; ++t) {
+    const int idx = tid + 256 * t, g = idx % PG, i = i0 + g * 4;
+    p_pl[t] = idx / PG;
+    p_col[t] = (idx < BI * 8 && i < a.NI) ? (unsigned)i * pes : BUF_OOB;
+  }
+#pragma unroll
+  for (int t = 0; t < QL; ++t) {
+    const int idx = tid + 256 * t, g = idx % QG, j = j0 + g * 4;
+    q_pl[t] = idx / QG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = j + r;
+      int tap = 0, cq = jj;
+      if (a.taps != 1) { tap = jj / a.Cq; cq = jj - tap * a.Cq; }
+      const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+      q_dyx[t][r] = (dy << 8) | (dx & 0xff);
+      q_col[t][r] = (idx < BJ * 8 && jj < a.J) ? (unsigned)((dy * a.W + dx) * a.ldq + cq) * qes : BUF_OOB;
+    }
+  }
   f32x4 preg[PL], qreg[QL];
   auto gload = [&](int chunk) {
     const int mb = chunk * BK;
 #pragma unroll
     for (int t = 0; t < PL; ++t) {
-      const int idx = tid + 256 * t;
-      const int pl = idx / PG, g = idx % PG;
-      const int m = mb + pl, i = i0 + g * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < BI * 8 && m < a.M && i < a.NI) {
-        const float* p = a.P + (long)m * a.ldp + i;
-        if (pvec) v = *reinterpret_cast<const f32x4*>(p);
-        else
+      const int m = mb + p_pl[t];
+      const unsigned base = (m < a.M && p_col[t] != BUF_OOB) ? (unsigned)m * (unsigned)a.ldp * pes + p_col[t] : BUF_OOB;
+      if (pvec) preg[t] = load4(rP, base, a.pbf16);
+      else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (i + r < a.NI) v[r] = p[r];
+        for (int r = 0; r < 4; ++r)
+          v[r] = load1(rP, (base != BUF_OOB && (int)(p_col[t] / pes) + r < a.NI) ? base + r * pes : BUF_OOB, a.pbf16);
+        preg[t] = v;
       }
-      preg[t] = v;
     }
 #pragma unroll
     for (int t = 0; t < QL; ++t) {
-      const int idx = tid + 256 * t;
-      const int pl = idx / QG, g = idx % QG;
-      const int m = mb + pl, j = j0 + g * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < BJ * 8 && m < a.M && j < a.J) {
-        const int rem = m % HW, y = rem / a.W, x = rem % a.W;
-        if (qvec) {
-          int tap = 0, cq = j;
-          if (a.taps != 1) { tap = j / a.Cq; cq = j - tap * a.Cq; }
-          const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
-          if ((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W)
-            v = *reinterpret_cast<const f32x4*>(a.Q + (long)(m + dy * a.W + dx) * a.ldq + cq);
-        } else {
+      const int m = mb + q_pl[t];
+      const int rem = m % HW, y = rem / a.W, x = rem - y * a.W;
+      const unsigned rowb = (unsigned)m * (unsigned)a.ldq * qes;
+      auto okr = [&](int r) {
+        const int dy = q_dyx[t][r] >> 8, dx = (int)(signed char)(q_dyx[t][r] & 0xff);
+        return m < a.M && q_col[t][r] != BUF_OOB && (unsigned)(y + dy) < (unsigned)a.H &&
+               (unsigned)(x + dx) < (unsigned)a.W;
+      };
+      if (qvec) qreg[t] = load4(rQ, okr(0) ? rowb + q_col[t][0] : BUF_OOB, a.qbf16);
+      else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int jj = j + r;
-            if (jj >= a.J) continue;
-            int tap = 0, cq = jj;
-            if (a.taps != 1) { tap = jj / a.Cq; cq = jj - tap * a.Cq; }
-            const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
-            if ((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W)
-              v[r] = a.Q[(long)(m + dy * a.W + dx) * a.ldq + cq];
-          }
-        }
+        for (int r = 0; r < 4; ++r) v[r] = load1(rQ, okr(r) ? rowb + q_col[t][r] : BUF_OOB, a.qbf16);
+        qreg[t] = v;
       }
-      qreg[t] = v;
     }
   };
   constexpr int LDP = BI + 4, LDQ = BJ + 4, STAGE = BK * (LDP + LDQ);
@@ -533,6 +563,25 @@ struct ProfScope {
   }
 };
 
+void prof_scope_begin(int cls, double flops, double bytes, hipStream_t st) {
+  if (!g_prof_on) return;
+  ProfClass* c = &g_prof[cls];
+  if (c->used + 2 > c->ev.size()) {
+    c->ev.resize(c->used + 2);
+    (void)hipEventCreate(&c->ev[c->used]);
+    (void)hipEventCreate(&c->ev[c->used + 1]);
+  }
+  c->flops += flops;
+  c->bytes += bytes;
+  (void)hipEventRecord(c->ev[c->used], st);
+}
+void prof_scope_end(int cls, hipStream_t st) {
+  if (!g_prof_on) return;
+  ProfClass* c = &g_prof[cls];
+  (void)hipEventRecord(c->ev[c->used + 1], st);
+  c->used += 2;
+}
+
 void prof_begin() {
   for (auto& c : g_prof) { c.used = 0; c.flops = 0.0; c.bytes = 0.0; }
   g_prof_on = true;
@@ -661,6 +710,7 @@ int wgrad_gemm(WgradArgs a, int S, hipStream_t st) {
   a.M = a.B * a.H * a.W;
   a.J = a.taps * a.Cq;
   if (a.M <= 0 || a.NI <= 0 || a.J <= 0) return NFK_OK;
+  if ((long)a.M * a.ldp * 4 >= 0x7fffffffL || (long)a.M * a.ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
   if (a.NI > 96) return launch_wgrad<4, 4, 2, 2>(a, S, st, NFK_PROF_WGRAD_WIDE);
   switch (ceil_div(a.NI, 16)) {
     case 1: return launch_wgrad<1, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);

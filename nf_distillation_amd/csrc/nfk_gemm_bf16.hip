@@ -1,0 +1,389 @@
+// nfk GEMM engine, bf16-operand / fp32-accumulate variant (throughput mode, BASELINE.json config 2):
+// the same implicit-GEMM convolution as nfk_gemm.hip on v_mfma_f32_16x16x32_bf16.
+//
+//   * the 512-wide hidden tensors (h1, h2 and their gradients) live in HBM as bf16: half the bytes
+//   * weights are repacked to bf16 [N][Kp64] once per forward (fp32 master weights stay with Adam)
+//   * k-chunk = 64 bf16 = 128-byte LDS rows, the same XOR-swizzled geometry as the f32 kernel:
+//     one ds_read_b128 yields a lane's 8 consecutive k of one MFMA operand, conflict-free
+//   * accumulation, ActNorm scale/bias, ReLU, masks and per-channel sums stay fp32; narrow inputs
+//     (z1, g_a3: C <= 96 channels) stay fp32 in HBM and are converted while staging (XF32)
+#include "nfk_internal.h"
+
+namespace nfk {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
+
+constexpr int BKH = 64;                 // bf16 elements per k-chunk
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4b ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ float ld4f(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ int xcd_remap_b(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+// byte offset of 16-byte slot `slot` (0..7) of tile row `row` (128-byte rows, XOR swizzle)
+__device__ __forceinline__ int lds_boff(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int TN, int TM, int WN, int WM, bool XF32>
+__global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
+  static_assert(WN * WM == 4, "256-thread workgroups");
+  constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
+  constexpr int WL = (BN * 8 + 255) / 256, XL = BM / 32;
+  constexpr int STAGE = (BN + BM) * 128;  // bytes
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid % WN, wm = wid / WN;
+  const int nNB = (a.N + BN - 1) / BN, nMB = (a.M + BM - 1) / BM;
+  const int bid = xcd_remap_b(blockIdx.x, nNB * nMB);
+  const int n0 = (bid % nNB) * BN, m0 = (bid / nNB) * BM;
+  const int HW = a.H * a.W;
+  constexpr int XE = XF32 ? 4 : 2;  // bytes per X element
+  const int S = gridDim.y, z = blockIdx.y;
+  const int c_begin = (int)((long)a.nkchunks * z / S), c_end = (int)((long)a.nkchunks * (z + 1) / S);
+
+  const __amdgpu_buffer_rsrc_t rX = rsrc_of(a.X, (unsigned)((long)a.M * a.ldx * XE));
+  const __amdgpu_buffer_rsrc_t rW = rsrc_of(a.Wt, (unsigned)((long)a.N * a.Kp * 2));
+  const int lq = tid & 7, lr = tid >> 3;
+  unsigned rowoff[XL], woff[WL];
+  int yx[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int m = m0 + lr + 32 * i;
+    const int rem = m % HW;
+    rowoff[i] = m < a.M ? (unsigned)m * (unsigned)a.ldx * XE : OOB;
+    yx[i] = ((rem / a.W) << 16) | (rem % a.W);
+  }
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    const int r = (tid + 256 * i) >> 3, n = n0 + r;
+    woff[i] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.Kp * 2u : OOB;
+  }
+  // granularity at which 8 consecutive k stay inside one tap and are vector-loadable
+  const bool v8 = ((a.Cin | a.ldx) & 7) == 0;   // bf16: one 16-B load; f32: two 16-B loads, one decode
+  const bool v4 = ((a.Cin | a.ldx) & 3) == 0;   // f32 only: two 16-B loads, decoded separately
+  const bool unif = v8 && (a.Cin % BKH) == 0;
+
+  u32x4b wreg[WL], xreg[XL];
+  auto decode = [&](int k, unsigned& add, bool& kok) {
+    int tap = 0, ci = k;
+    if (a.taps != 1) { tap = k / a.Cin; ci = k - tap * a.Cin; }
+    const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+    add = (unsigned)((dy * a.W + dx) * a.ldx + ci) * XE;
+    kok = k < a.K;
+    return (dy << 8) | (dx & 0xff);
+  };
+  auto inb = [&](int i, int dyx) {
+    const int dy = dyx >> 8, dx = (int)(signed char)(dyx & 0xff);
+    const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
+    return (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+  };
+  auto gload = [&](int chunk) {
+    const int k = chunk * BKH + lq * 8;
+#pragma unroll
+    for (int i = 0; i < WL; ++i) wreg[i] = ld16(rW, woff[i] + (unsigned)k * 2u);
+    if (!XF32) {
+      if (v8) {
+        unsigned add; bool kok;
+        const int dyx = decode(unif ? chunk * BKH : k, add, kok);
+        if (unif) add += (unsigned)lq * 8u * XE;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) xreg[i] = ld16(rX, (kok && inb(i, dyx)) ? rowoff[i] + add : OOB);
+      } else {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) xreg[i] = u32x4b{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          unsigned add; bool kok;
+          const int dyx = decode(k + j, add, kok);
+#pragma unroll
+          for (int i = 0; i < XL; ++i) {
+            const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+                rX, (int)((kok && inb(i, dyx)) ? rowoff[i] + add : OOB), 0, 0);
+            xreg[i][j >> 1] |= (unsigned)h << ((j & 1) * 16);
+          }
+        }
+      }
+    } else {
+      if (v4) {
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          unsigned add; bool kok;
+          const int dyx = decode(k + 4 * hlf, add, kok);
+#pragma unroll
+          for (int i = 0; i < XL; ++i) {
+            const f32x4 f = __builtin_bit_cast(f32x4, ld16(rX, (kok && inb(i, dyx)) ? rowoff[i] + add : OOB));
+            xreg[i][2 * hlf] = pack2(f[0], f[1]);
+            xreg[i][2 * hlf + 1] = pack2(f[2], f[3]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          unsigned add0, add1; bool k0, k1;
+          const int d0 = decode(k + 2 * jj, add0, k0), d1 = decode(k + 2 * jj + 1, add1, k1);
+#pragma unroll
+          for (int i = 0; i < XL; ++i) {
+            const float f0 = ld4f(rX, (k0 && inb(i, d0)) ? rowoff[i] + add0 : OOB);
+            const float f1 = ld4f(rX, (k1 && inb(i, d1)) ? rowoff[i] + add1 : OOB);
+            xreg[i][jj] = pack2(f0, f1);
+          }
+        }
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* Ws = smem_b + buf * STAGE;
+    char* Xs = Ws + BN * 128;
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int r = (tid + 256 * i) >> 3;
+      if (r < BN) *reinterpret_cast<u32x4b*>(Ws + lds_boff(r, lq)) = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) *reinterpret_cast<u32x4b*>(Xs + lds_boff(lr + 32 * i, lq)) = xreg[i];
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (c_begin < c_end) {
+    gload(c_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  const int r16 = lane & 15, q4 = lane >> 4;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) gload(c + 1);
+    const char* Ws = smem_b + buf * STAGE;
+    const char* Xs = Ws + BN * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[TN], fb[TM];
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        fa[t] = *reinterpret_cast<const bf16x8*>(Ws + lds_boff(wn * 16 * TN + t * 16 + r16, ks * 4 + q4));
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+        fb[t] = *reinterpret_cast<const bf16x8*>(Xs + lds_boff(wm * 16 * TM + t * 16 + r16, ks * 4 + q4));
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tn], fb[tm], acc[tn][tm], 0, 0, 0);
+    }
+    if (c + 1 < c_end) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue (fp32 math; bf16 or f32 stores) ----------------
+  const int nq = q4 * 4, mi = r16;
+  const bool n4 = (a.N & 3) == 0;
+  f32x4 cdl[TN], cdb[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) { cdl[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cdb[t] = cdl[t]; }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * 16 * TN + tn * 16 + nq;
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {1.f, 1.f, 1.f, 1.f};
+    if (a.epi != EPI_RAW) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) {
+          if (a.epi == EPI_AN_RELU) e0[r] = a.e0[n + r];
+          e1[r] = a.e1[n + r];
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * 16 * TM + tm * 16 + mi;
+      if (m >= a.M || n >= a.N) continue;
+      f32x4 v = acc[tn][tm];
+      if (a.epi == EPI_AN_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf((v[r] + e0[r]) * e1[r], 0.f);
+      } else if (a.epi == EPI_DGRAD) {
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        const __bf16* hp = reinterpret_cast<const __bf16*>(a.hprev) + (long)m * a.ldh + n;
+        if (n + 3 < a.N && ((a.ldh & 3) == 0)) {
+          const bf16x4 hb = *reinterpret_cast<const bf16x4*>(hp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (float)hb[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < a.N) h[r] = (float)hp[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = v[r];
+          cdl[tn][r] += g * h[r];
+          v[r] = h[r] > 0.f ? g * e1[r] : 0.f;
+          cdb[tn][r] += v[r];
+        }
+      }
+      if (a.obf16) {
+        __bf16* op = reinterpret_cast<__bf16*>(a.out) + (long)m * a.ldo + n;
+        if (n4 && ((a.ldo & 3) == 0) && n + 3 < a.N) {
+          u32x2b pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+          *reinterpret_cast<u32x2b*>(op) = pk;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < a.N) op[r] = (__bf16)v[r];
+        }
+      } else {
+        float* op = a.out + (long)z * a.slab_stride + (long)m * a.ldo + n;
+        if (n4 && ((a.ldo & 3) == 0) && n + 3 < a.N) *reinterpret_cast<f32x4*>(op) = v;
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < a.N) op[r] = v[r];
+      }
+    }
+  }
+  if (a.epi == EPI_DGRAD) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_b);  // [WM][2][BN]
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0 = cdl[tn][r], s1 = cdb[tn][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s0 += __shfl_xor(s0, off, 64);
+          s1 += __shfl_xor(s1, off, 64);
+        }
+        if (mi == 0) {
+          const int nl = wn * 16 * TN + tn * 16 + nq + r;
+          red[(wm * 2 + 0) * BN + nl] = s0;
+          red[(wm * 2 + 1) * BN + nl] = s1;
+        }
+      }
+    __syncthreads();
+    const int mb = bid / nNB;
+    for (int t = tid; t < 2 * BN; t += 256) {
+      const int which = t / BN, nl = t % BN;
+      if (n0 + nl < a.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + nl];
+        a.colsum[((long)mb * 2 + which) * a.N + n0 + nl] = s;
+      }
+    }
+  }
+}
+
+// conv.weight [Cout][Cin][taps] (fp32) -> bf16 wt [Cout][Kp64] and wd [Cin][Kp64(taps*Cout)] (flipped taps)
+__global__ void repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ descs) {
+  const nfk_repack_desc d = descs[blockIdx.y];
+  const int Kp = (d.taps * d.Cin + BKH - 1) / BKH * BKH, Kpd = (d.taps * d.Cout + BKH - 1) / BKH * BKH;
+  const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
+  __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
+  __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d;
+       t += (long)gridDim.x * blockDim.x) {
+    if (t < total_f) {
+      const int co = t / Kp, k = t % Kp;
+      float v = 0.f;
+      if (k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];
+      wt[t] = (__bf16)v;
+    } else {
+      const long u = t - total_f;
+      const int ci = u / Kpd, k = u % Kpd;
+      float v = 0.f;
+      if (k < d.taps * d.Cout) v = d.w[((long)(k % d.Cout) * d.Cin + ci) * d.taps + (d.taps - 1 - k / d.Cout)];
+      wd[u] = (__bf16)v;
+    }
+  }
+}
+
+template <int TN, int TM, int WN, int WM>
+static int launch_bf16(const ConvGemmArgs& a, int S, hipStream_t st, int cls) {
+  constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
+  constexpr size_t lds = 2 * (BN + BM) * 128;
+  dim3 grid(ceil_div(a.N, BN) * ceil_div(a.M, BM), S);
+  static bool attr0 = false, attr1 = false;
+  prof_scope_begin(cls, 2.0 * a.M * (double)a.N * a.K,
+                   (a.xf32 ? 4.0 : 2.0) * a.M * a.Cin + 2.0 * a.N * a.K + (a.obf16 ? 2.0 : 4.0 * S) * a.M * a.N, st);
+  if (a.xf32) {
+    if (!attr1 && lds > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_kernel<TN, TM, WN, WM, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr1 = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, TM, WN, WM, true>), grid, dim3(256), lds, st, a);
+  } else {
+    if (!attr0 && lds > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_kernel<TN, TM, WN, WM, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr0 = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, TM, WN, WM, false>), grid, dim3(256), lds, st, a);
+  }
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int padded_k_bf16(int K) { return ceil_div(K, BKH) * BKH; }
+
+int conv_splitk_bf16(int M, int N, int K, int epi) {
+  if (epi != EPI_RAW || N > 96) return 1;
+  const int nMB = ceil_div(M, 128), nk = ceil_div(K, BKH);
+  int S = ceil_div(512, nMB);
+  if (S > nk / 2) S = nk / 2;
+  if (S < 1) S = 1;
+  if (S > 32) S = 32;
+  return S;
+}
+static bool big_tiles(int M, int N) { return (long)ceil_div(N, 128) * ceil_div(M, 128) >= 256; }
+int conv_mblocks_bf16(int M, int N) { return N > 96 ? ceil_div(M, big_tiles(M, N) ? 128 : 64) : ceil_div(M, 128); }
+
+int conv_gemm_bf16(ConvGemmArgs a, hipStream_t st) {
+  if (a.taps != 1 && a.taps != 9) return NFK_ERR_ARG;
+  a.K = a.taps * a.Cin;
+  a.M = a.B * a.H * a.W;
+  a.nkchunks = ceil_div(a.K, BKH);
+  if (a.Kp < a.nkchunks * BKH) return NFK_ERR_ARG;
+  if (a.M <= 0 || a.N <= 0) return NFK_OK;
+  if (!a.xf32 && (((a.Cin | a.ldx) & 7) != 0) && false) return NFK_ERR_ARG;
+  if ((long)a.M * a.ldx * 4 >= 0x7fffffffL || (long)a.N * a.Kp * 2 >= 0x7fffffffL) return NFK_ERR_ARG;
+  const int S = conv_splitk_bf16(a.M, a.N, a.K, a.epi);
+  if (a.N > 96)
+    return big_tiles(a.M, a.N) ? launch_bf16<4, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128)
+                               : launch_bf16<2, 2, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE64);
+  switch (ceil_div(a.N, 16)) {
+    case 1: return launch_bf16<1, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    case 2: return launch_bf16<2, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    case 3: return launch_bf16<3, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    case 4: return launch_bf16<4, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+    default: return launch_bf16<6, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
+  }
+}
+
+int repack_batch_bf16(const nfk_repack_desc* descs, int n, hipStream_t st) {
+  if (n <= 0) return NFK_OK;
+  hipLaunchKernelGGL(repack_batch_bf16_kernel, dim3(64, n), dim3(256), 0, st, descs);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+}  // namespace nfk

@@ -21,7 +21,9 @@ struct ConvGemmArgs {
   const float* hprev;  // DGRAD: post-ReLU activation of the layer being differentiated
   int ldh;
   float* colsum;       // DGRAD: [mblocks][2][N] partial column sums (dlogs, dbias)
-  int nkchunks;        // ceil(K/32)
+  int nkchunks;        // ceil(K/32)  (bf16 kernel: ceil(K/64))
+  // bf16 mode (conv_gemm_bf16): Wt, and unless xf32 also X, are bf16; hprev is bf16; out is bf16 when obf16
+  int xf32, obf16;
 };
 
 struct WgradArgs {
@@ -29,6 +31,7 @@ struct WgradArgs {
   const float* Q; int ldq, Cq, taps;
   int B, H, W, M, J;   // J = taps*Cq
   float* out; long slab_stride;  // out[slab][i*J + j]
+  int pbf16, qbf16;              // P / Q stored as bf16 (converted to f32 while staging)
 };
 
 struct ChanMixArgs {
@@ -111,6 +114,13 @@ int padded_k(int K);
 int conv_splitk(int M, int N, int K, int epi);
 int conv_mblocks(int M, int N);
 int conv_gemm(ConvGemmArgs a, hipStream_t st);
+int conv_gemm_bf16(ConvGemmArgs a, hipStream_t st);
+int padded_k_bf16(int K);
+int conv_splitk_bf16(int M, int N, int K, int epi);
+int conv_mblocks_bf16(int M, int N);
+int repack_batch_bf16(const nfk_repack_desc* descs, int n, hipStream_t st);
+void prof_scope_begin(int cls, double flops, double bytes, hipStream_t st);
+void prof_scope_end(int cls, hipStream_t st);
 int wgrad_splits(int M, int NI, int J);
 int wgrad_gemm(WgradArgs a, int S, hipStream_t st);
 int repack_weights(const float* W, int Cout, int Cin, int taps, float* Wt, float* Wd, hipStream_t st);

@@ -51,6 +51,7 @@ class FlowEngine:
         self.is_1d = any(isinstance(l, M.FlowStep) and l.is_1d for l in layers)
         self._params = None
         self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
+        self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
     def params(self):
@@ -75,6 +76,14 @@ class FlowEngine:
                 v += t._version
         return v
 
+    def set_compute_dtype(self, name):
+        """"f32" (parity mode, default) or "bf16" (bf16 operands, fp32 accumulate in the coupling-net convs)."""
+        if name not in ("f32", "bf16"):
+            raise ValueError("compute dtype must be 'f32' or 'bf16'")
+        want = name == "bf16"
+        if want != self.bf16:
+            self.bf16, self.state, self.key = want, None, None
+
     def mark_dirty(self):
         if self.state is not None:
             self.state["version"] = None
@@ -89,7 +98,8 @@ class FlowEngine:
         else:
             Cc, H, W = in_shape
         prep_floats = 0
-        pack_floats = 0
+        pack_floats = 0   # Split2d convs (always fp32)
+        step_pack = 0     # FlowStep convs: elements of fp32 or bf16
         plan = []  # (rec, offsets)
         for i, layer in enumerate(self.layers):
             r = _Rec()
@@ -114,14 +124,16 @@ class FlowEngine:
                 prep_floats = o
                 if not layer.is_1d:
                     Ch, hid = Cc // 2, r.hid
-                    o = pack_floats
-                    for name, n in (("wt1", hid * lib.nfk_padded_k(9 * Ch)), ("wd1", Ch * lib.nfk_padded_k(9 * hid)),
-                                    ("wt2", hid * lib.nfk_padded_k(hid)), ("wd2", hid * lib.nfk_padded_k(hid)),
-                                    ("wt3", r.Cout * lib.nfk_padded_k(9 * hid)),
-                                    ("wd3", hid * lib.nfk_padded_k(9 * r.Cout))):
+                    pk = lib.nfk_padded_k_bf16 if self.bf16 else lib.nfk_padded_k
+                    if self.bf16 and hid % 8:
+                        raise ValueError("bf16 mode needs hidden_channels % 8 == 0")
+                    o = step_pack
+                    for name, n in (("wt1", hid * pk(9 * Ch)), ("wd1", Ch * pk(9 * hid)),
+                                    ("wt2", hid * pk(hid)), ("wd2", hid * pk(hid)),
+                                    ("wt3", r.Cout * pk(9 * hid)), ("wd3", hid * pk(9 * r.Cout))):
                         off[name] = o
-                        o += _a4(n)
-                    pack_floats = o
+                        o += (n + 7) & ~7
+                    step_pack = o
                 plan.append((r, off))
             elif isinstance(layer, M.Split2d):
                 r.kind, r.C, r.H, r.W = "split", Cc, H, W
@@ -140,7 +152,9 @@ class FlowEngine:
 
         prep_buf = torch.zeros(max(prep_floats, 4), dtype=torch.float32, device=device)
         pack_buf = torch.zeros(max(pack_floats, 4), dtype=torch.float32, device=device)
-        pb, kb = prep_buf.data_ptr(), pack_buf.data_ptr()
+        step_buf = torch.zeros(max(step_pack, 8), dtype=torch.bfloat16 if self.bf16 else torch.float32, device=device)
+        pb, kb, sb, esz = prep_buf.data_ptr(), pack_buf.data_ptr(), step_buf.data_ptr(), (2 if self.bf16 else 4)
+        step_repack = []
         keep = []  # tensors that must stay alive (perm indices, zero vectors)
         any_dense = 0
         for r, off in plan:
@@ -181,11 +195,12 @@ class FlowEngine:
                         setattr(d, nm, pb + 4 * off[nm])
                     cs = Step2d()
                     cs.B, cs.H, cs.W, cs.C, cs.hidden, cs.Cout, cs.additive = B, r.H, r.W, r.C, r.hid, r.Cout, r.additive
+                    cs.bf16 = 1 if self.bf16 else 0
                     cs.b1, cs.b2, cs.bias3 = ptr(blk[0].actnorm.bias), ptr(blk[2].actnorm.bias), ptr(blk[4].conv.bias)
                     for nm in ("Wf", "cf", "Wi", "ci", "dld", "es1", "es2", "es3"):
                         setattr(cs, nm, pb + 4 * off[nm])
                     for nm in ("wt1", "wt2", "wt3", "wd1", "wd2", "wd3"):
-                        setattr(cs, nm, kb + 4 * off[nm])
+                        setattr(cs, nm, sb + esz * off[nm])
                     r.cs = cs
                     Ch = r.C // 2
                     for w, co, ci, taps, a, b in ((blk[0].conv.weight, r.hid, Ch, 9, "wt1", "wd1"),
@@ -195,9 +210,9 @@ class FlowEngine:
                         if tuple(w.shape) != (co, ci, 3 if taps == 9 else 1, 3 if taps == 9 else 1):
                             raise ValueError(f"layer {r.idx}: unexpected conv weight shape {tuple(w.shape)}")
                         rd = RepackDesc()
-                        rd.w, rd.wt, rd.wd = ptr(w), kb + 4 * off[a], kb + 4 * off[b]
+                        rd.w, rd.wt, rd.wd = ptr(w), sb + esz * off[a], sb + esz * off[b]
                         rd.Cout, rd.Cin, rd.taps = co, ci, taps
-                        repack_descs.append(rd)
+                        step_repack.append(rd)
                 else:
                     from .tabular import TabStep
                     r.tab = TabStep(r, B, pb, off)
@@ -221,6 +236,8 @@ class FlowEngine:
             "prep_dev": capi.struct_array_to_device(prep_descs, device), "n_prep": len(prep_descs),
             "prep_host": prep_descs,
             "repack_dev": capi.struct_array_to_device(repack_descs, device), "n_repack": len(repack_descs),
+            "step_repack_dev": capi.struct_array_to_device(step_repack, device), "n_step_repack": len(step_repack),
+            "step_buf": step_buf,
             "any_dense": any_dense, "version": None, "has_inverse": False, "sig": self._signature(),
             "out_shape": (Cc, H, W), "grad_sig": None, "grad_dev": None,
         }
@@ -247,6 +264,8 @@ class FlowEngine:
         lib, s = capi.lib(), capi.stream()
         check(lib.nfk_prep(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, s), "nfk_prep")
         check(lib.nfk_repack_batch(ptr(st["repack_dev"]), st["n_repack"], s), "nfk_repack_batch")
+        repack = lib.nfk_repack_batch_bf16 if self.bf16 else lib.nfk_repack_batch
+        check(repack(ptr(st["step_repack_dev"]), st["n_step_repack"], s), "nfk_repack_batch(step convs)")
         st["version"], st["has_inverse"] = ver, bool(want_inverse)
 
     # ------------------------------------------------------------------ public entry points

@@ -441,6 +441,12 @@ class Glow(nn.Module):
         outs = self.flow._decode_all(z, y_onehot, temperature, eps)
         return outs if isinstance(self.flow, FlowNetGetAllOutputs) else outs[-1]
 
+    def set_compute_dtype(self, name):
+        """"f32": the reference's precision (parity mode).  "bf16": bf16 operands with fp32 accumulation
+        in the coupling-net convolutions (throughput mode; everything else stays fp32)."""
+        self.flow.engine().set_compute_dtype(name)
+        return self
+
     def set_actnorm_init(self):
         for _, module in self.named_modules():
             if isinstance(module, (ActNorm2d, ActNorm1d)):
