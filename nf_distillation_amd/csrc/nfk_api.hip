@@ -23,9 +23,9 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;
   const int Ch = s->C / 2, hid = s->hidden;
   w.S1 = splitk_of(s->bf16, (int)M, Ch, 9 * hid);
-  w.S3w = wgrad_splits((int)M, s->Cout, 9 * hid);
-  w.S2w = wgrad_splits((int)M, hid, hid);
-  w.S1w = wgrad_splits((int)M, hid, 9 * Ch);
+  w.S3w = s->bf16 ? wgrad_splits_bf16((int)M, s->Cout, 9 * hid) : wgrad_splits((int)M, s->Cout, 9 * hid);
+  w.S2w = s->bf16 ? wgrad_splits_bf16((int)M, hid, hid) : wgrad_splits((int)M, hid, hid);
+  w.S1w = s->bf16 ? wgrad_splits_bf16((int)M, hid, 9 * Ch) : wgrad_splits((int)M, hid, 9 * Ch);
   w.mb = s->bf16 ? conv_mblocks_bf16((int)M, hid) : conv_mblocks((int)M, hid);
   size_t o = 0;
   w.ga3 = o; o += align4(M * s->Cout);
@@ -235,7 +235,7 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
   w3.B = B; w3.H = H; w3.W = W; w3.out = wslab; w3.slab_stride = (long)Cout * 9 * hid;
   w3.qbf16 = bf;
-  NFK_TRY(wgrad_gemm(w3, L.S3w, st));
+  NFK_TRY(bf ? wgrad_gemm_bf16(w3, L.S3w, st) : wgrad_gemm(w3, L.S3w, st));
   NFK_TRY(wgrad_finalize(wslab, L.S3w, w3.slab_stride, Cout, hid, 9, g->g_w3, st));
   ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD, bf, 1, bf);
   d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
@@ -246,7 +246,7 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
   w2.B = B; w2.H = H; w2.W = W; w2.out = wslab; w2.slab_stride = (long)hid * hid;
   w2.pbf16 = bf; w2.qbf16 = bf;
-  NFK_TRY(wgrad_gemm(w2, L.S2w, st));
+  NFK_TRY(bf ? wgrad_gemm_bf16(w2, L.S2w, st) : wgrad_gemm(w2, L.S2w, st));
   NFK_TRY(wgrad_finalize(wslab, L.S2w, w2.slab_stride, hid, hid, 1, g->g_w2, st));
   ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
   d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
@@ -257,7 +257,7 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = z; w1.ldq = C; w1.Cq = Ch; w1.taps = 9;
   w1.B = B; w1.H = H; w1.W = W; w1.out = wslab; w1.slab_stride = (long)hid * 9 * Ch;
   w1.pbf16 = bf;
-  NFK_TRY(wgrad_gemm(w1, L.S1w, st));
+  NFK_TRY(bf ? wgrad_gemm_bf16(w1, L.S1w, st) : wgrad_gemm(w1, L.S1w, st));
   NFK_TRY(wgrad_finalize(wslab, L.S1w, w1.slab_stride, hid, Ch, 9, g->g_w1, st));
   ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
   NFK_TRY(run_conv(bf, d1a, st));

@@ -386,4 +386,225 @@ int repack_batch_bf16(const nfk_repack_desc* descs, int n, hipStream_t st) {
   return NFK_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad on the bf16 matrix cores: out[slab][i][j] = sum_m P[m][i] * Qim2col[m][j]
+// Tiles are staged pixel-major [64 pixels][channels] exactly as they sit in HBM (16-byte copies);
+// the MFMA operands need 8 consecutive PIXELS of one channel per lane, which the gfx950 transpose
+// read ds_read_b64_tr_b16 delivers straight from that image (4 pixels x 16 channels per 16 lanes).
+// Row stride = 32 B * odd so the 8 rows a half-wave touches fall on distinct banks.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int WPX = 64;  // pixels per chunk (two 32-deep MFMA k-steps)
+
+__host__ __device__ constexpr int wg_stride(int ch) { return ((ch / 16) & 1) ? ch * 2 : ch * 2 + 32; }  // bytes
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int c0, int ks, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const char* a0 = tile + (32 * ks + 4 * g + q) * stride + (c0 + 4 * p) * 2;
+  typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0 + 16 * stride));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TN, int TM, int WN, int WM>
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
+  constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
+  constexpr int SP = wg_stride(BI), SQ = wg_stride(BJ);
+  constexpr int STAGE = WPX * (SP + SQ);
+  constexpr int PL = (WPX * BI / 8 + 255) / 256, QL = (WPX * BJ / 8 + 255) / 256;
+  constexpr int PG = BI / 8, QG = BJ / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid % WN, wm = wid / WN;
+  const int nIB = (a.NI + BI - 1) / BI, nJB = (a.J + BJ - 1) / BJ;
+  const int bid = xcd_remap_b(blockIdx.x, nIB * nJB);
+  const int i0 = (bid % nIB) * BI, j0 = (bid / nIB) * BJ;
+  const int HW = a.H * a.W;
+  const int S = gridDim.y, z = blockIdx.y;
+  const int nchunks = (a.M + WPX - 1) / WPX;
+  const int c_begin = (int)((long)nchunks * z / S), c_end = (int)((long)nchunks * (z + 1) / S);
+  const unsigned pes = a.pbf16 ? 2u : 4u, qes = a.qbf16 ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rP = rsrc_of(a.P, (unsigned)((long)a.M * a.ldp * pes));
+  const __amdgpu_buffer_rsrc_t rQ = rsrc_of(a.Q, (unsigned)((long)a.M * a.ldq * qes));
+  const bool pv = ((a.NI | a.ldp) & 7) == 0, qv = ((a.Cq | a.ldq) & 7) == 0;
+
+  // 8 consecutive elements starting at byte offset `off` (OOB -> zeros), widened/narrowed to bf16
+  auto load8 = [&](__amdgpu_buffer_rsrc_t r, unsigned off, bool isbf) {
+    if (isbf) return ld16(r, off);
+    const f32x4 f0 = __builtin_bit_cast(f32x4, ld16(r, off));
+    const f32x4 f1 = __builtin_bit_cast(f32x4, ld16(r, off == OOB ? OOB : off + 16u));
+    return u32x4b{pack2(f0[0], f0[1]), pack2(f0[2], f0[3]), pack2(f1[0], f1[1]), pack2(f1[2], f1[3])};
+  };
+  auto load1h = [&](__amdgpu_buffer_rsrc_t r, unsigned off, bool isbf) -> unsigned {
+    if (isbf) return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0);
+    const __bf16 h = (__bf16)ld4f(r, off);
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+  };
+
+  int p_pl[PL], q_pl[QL];
+  unsigned p_col[PL];
+#pragma unroll
+  for (int t = 0; t < PL; ++t) {
+    const int idx = tid + 256 * t, g = idx % PG, i = i0 + g * 8;
+    p_pl[t] = idx / PG;
+    p_col[t] = (idx < WPX * PG && i < a.NI) ? (unsigned)i : OOB;   // element index, OOB if the group is outside
+  }
+#pragma unroll
+  for (int t = 0; t < QL; ++t) q_pl[t] = (tid + 256 * t) / QG;
+
+  u32x4b preg[PL], qreg[QL];
+  auto gload = [&](int chunk) {
+    const int mb = chunk * WPX;
+#pragma unroll
+    for (int t = 0; t < PL; ++t) {
+      const int m = mb + p_pl[t];
+      const bool ok = m < a.M && p_col[t] != OOB;
+      const unsigned base = ((unsigned)m * (unsigned)a.ldp + p_col[t]) * pes;
+      if (pv) preg[t] = load8(rP, ok ? base : OOB, a.pbf16);
+      else {
+        u32x4b v = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool oke = ok && (int)p_col[t] + e < a.NI;
+          v[e >> 1] |= load1h(rP, oke ? base + e * pes : OOB, a.pbf16) << ((e & 1) * 16);
+        }
+        preg[t] = v;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QL; ++t) {
+      const int idx = tid + 256 * t, g = idx % QG, j = j0 + g * 8;
+      const int m = mb + q_pl[t];
+      const int rem = m % HW, y = rem / a.W, x = rem - y * a.W;
+      const bool rowok = idx < WPX * QG && m < a.M;
+      auto elem_off = [&](int jj, bool& ok) {
+        int tap = 0, cq = jj;
+        if (a.taps != 1) { tap = jj / a.Cq; cq = jj - tap * a.Cq; }
+        const int dy = (a.taps == 1) ? 0 : tap / 3 - 1, dx = (a.taps == 1) ? 0 : tap % 3 - 1;
+        ok = rowok && jj < a.J && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
+        return (unsigned)((m + dy * a.W + dx) * a.ldq + cq) * qes;
+      };
+      if (qv) {
+        bool ok;
+        const unsigned off = elem_off(j, ok);
+        qreg[t] = load8(rQ, ok ? off : OOB, a.qbf16);
+      } else {
+        u32x4b v = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bool ok;
+          const unsigned off = elem_off(j + e, ok);
+          v[e >> 1] |= load1h(rQ, ok ? off : OOB, a.qbf16) << ((e & 1) * 16);
+        }
+        qreg[t] = v;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* Ps = smem_b + buf * STAGE;
+    char* Qs = Ps + WPX * SP;
+#pragma unroll
+    for (int t = 0; t < PL; ++t) {
+      const int idx = tid + 256 * t;
+      if (idx < WPX * PG) *reinterpret_cast<u32x4b*>(Ps + (idx / PG) * SP + (idx % PG) * 16) = preg[t];
+    }
+#pragma unroll
+    for (int t = 0; t < QL; ++t) {
+      const int idx = tid + 256 * t;
+      if (idx < WPX * QG) *reinterpret_cast<u32x4b*>(Qs + (idx / QG) * SQ + (idx % QG) * 16) = qreg[t];
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c_begin < c_end) {
+    gload(c_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) gload(c + 1);
+    const char* Ps = smem_b + buf * STAGE;
+    const char* Qs = Ps + WPX * SP;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[TN], fb[TM];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) fa[t] = tr_frag(Ps, SP, wn * 16 * TN + t * 16, ks, lane);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) fb[t] = tr_frag(Qs, SQ, wm * 16 * TM + t * 16, ks, lane);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tn], fb[tm], acc[tn][tm], 0, 0, 0);
+    }
+    if (c + 1 < c_end) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int iq = (lane >> 4) * 4, jl = lane & 15;
+  float* outp = a.out + (long)z * a.slab_stride;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int i = i0 + wn * 16 * TN + tn * 16 + iq, j = j0 + wm * 16 * TM + tm * 16 + jl;
+      if (j >= a.J) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (i + r < a.NI) outp[(long)(i + r) * a.J + j] = acc[tn][tm][r];
+    }
+}
+
+template <int TN, int TM, int WN, int WM>
+static int launch_wgrad_bf16(const WgradArgs& a, int S, hipStream_t st, int cls) {
+  constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
+  constexpr size_t lds = 2 * WPX * (wg_stride(BI) + wg_stride(BJ));
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<TN, TM, WN, WM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  dim3 grid(ceil_div(a.NI, BI) * ceil_div(a.J, BJ), S);
+  prof_scope_begin(cls, 2.0 * a.M * (double)a.NI * a.J,
+                   (a.pbf16 ? 2.0 : 4.0) * a.M * a.NI + (a.qbf16 ? 2.0 : 4.0) * a.M * a.Cq + 4.0 * S * a.NI * a.J, st);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<TN, TM, WN, WM>), grid, dim3(256), lds, st, a);
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int wgrad_splits_bf16(int M, int NI, int J) {
+  const int tiles = (NI > 96 ? ceil_div(NI, 128) : 1) * ceil_div(J, 128);
+  const int nchunks = ceil_div(M, WPX);
+  int S = ceil_div(768, tiles);
+  if (S > nchunks / 2) S = nchunks / 2;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  return S;
+}
+
+int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st) {
+  a.M = a.B * a.H * a.W;
+  a.J = a.taps * a.Cq;
+  if (a.M <= 0 || a.NI <= 0 || a.J <= 0) return NFK_OK;
+  if ((long)a.M * a.ldp * 4 >= 0x7fffffffL || (long)a.M * a.ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
+  if (a.NI > 96) return launch_wgrad_bf16<4, 4, 2, 2>(a, S, st, NFK_PROF_WGRAD_WIDE);
+  switch (ceil_div(a.NI, 16)) {
+    case 1: return launch_wgrad_bf16<1, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    case 2: return launch_wgrad_bf16<2, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    case 3: return launch_wgrad_bf16<3, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    case 4: return launch_wgrad_bf16<4, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+    default: return launch_wgrad_bf16<6, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
+  }
+}
+
 }  // namespace nfk
