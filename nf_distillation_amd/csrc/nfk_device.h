@@ -37,6 +37,28 @@ __device__ __forceinline__ float log_sigmoidf(float t) {
   return t >= 0.f ? -log1pf(expf(-t)) : t - log1pf(expf(t));
 }
 
+// Sum of S split-K slabs at one element, fixed order.  Loads are issued 8 (then 4) at a time so their
+// latencies overlap instead of forming an S-deep dependent chain.
+__device__ __forceinline__ float slab_sum(const float* __restrict__ a3, int S, long stride, long off) {
+  const float* p = a3 + off;
+  float v = 0.f;
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+    const float t0 = p[0], t1 = p[stride], t2 = p[2 * stride], t3 = p[3 * stride];
+    const float t4 = p[4 * stride], t5 = p[5 * stride], t6 = p[6 * stride], t7 = p[7 * stride];
+    v += ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
+    p += 8 * stride;
+  }
+  if (s + 4 <= S) {
+    const float t0 = p[0], t1 = p[stride], t2 = p[2 * stride], t3 = p[3 * stride];
+    v += (t0 + t1) + (t2 + t3);
+    p += 4 * stride;
+    s += 4;
+  }
+  for (; s < S; ++s) { v += p[0]; p += stride; }
+  return v;
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 #define NFK_LAUNCH_CHECK()                                   \

@@ -161,6 +161,19 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ 
   for (int i = threadIdx.x; i < d.n3; i += blockDim.x) d.es3[i] = expf(3.f * d.l3[i]);
 }
 
+// In-place reduction of the per-workgroup partial (gWf, gcf) slabs of every step into slab 0:
+// grid = (chunks of 256 elements, steps); element e of all slabs is touched by one thread only.
+__global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __restrict__ descs,
+                                                          const PrepGrad* __restrict__ grads) {
+  const PrepDesc d = descs[blockIdx.y];
+  const PrepGrad g = grads[blockIdx.y];
+  const int E = d.C * d.C + d.C;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (d.C == 0 || e >= E || g.nparts <= 1) return;
+  float* part = const_cast<float*>(g.part);
+  part[e] = slab_sum(part, g.nparts, E, e);
+}
+
 // Backward of prep: chain (gWf, gcf, G = sum_b g_logdet[b]) to the raw parameters; accumulates.
 //   part: [nparts][C*C + C] partial sums of  gWf[o][c] = sum_m gz[m][o] x[m][c],  gcf[o] = sum_m gz[m][o]
 __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
@@ -184,8 +197,7 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
 
   // reduce partials (fixed order): GWf -> T0 ; gcf -> T1[0..C)
   for (int idx = threadIdx.x; idx < CC + C; idx += blockDim.x) {
-    float s = 0.f;
-    for (int p = 0; p < g.nparts; ++p) s += g.part[(long)p * (CC + C) + idx];
+    const float s = g.part[idx];  // slab 0 holds the total (part_reduce_kernel)
     if (idx < CC) T0[idx] = s; else T1[idx - CC] = s;
   }
   __syncthreads();
@@ -252,8 +264,7 @@ __global__ void __launch_bounds__(256) prep_bwd_dense_kernel(const PrepDesc* __r
   blk_inverse(W, T0, AUG, C, sh);  // T0 = W^-1
   // recompute gWf_tot from partials
   for (int idx = threadIdx.x; idx < CC + C; idx += blockDim.x) {
-    float s = 0.f;
-    for (int p = 0; p < g.nparts; ++p) s += g.part[(long)p * (CC + C) + idx];
+    const float s = g.part[idx];
     if (idx < CC) AUG[idx] = s; else T1[idx - CC] = s;
   }
   __syncthreads();
@@ -307,7 +318,7 @@ __global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
         if (a.ga && c < a.Ch) {
           v = a.ga[(long)m * a.lda + c];
           if (a.gext) v += a.gext[(long)m * a.ldge + c];
-          for (int s = 0; s < a.S; ++s) v += a.slab[s * a.slab_stride + (long)m * a.Ch + c];
+          v += slab_sum(a.slab, a.S, a.slab_stride, (long)m * a.Ch + c);
         } else {
           v = a.x[(long)m * a.ldx + c];
         }
@@ -361,11 +372,6 @@ __global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
 // coupling tail (affine / additive), one workgroup per sample
 // ==========================================================================================
 
-__device__ __forceinline__ float slab_sum(const float* a3, int S, long stride, long off) {
-  float v = 0.f;
-  for (int s = 0; s < S; ++s) v += a3[s * stride + off];
-  return v;
-}
 
 __global__ void __launch_bounds__(1024) coupling_fwd_kernel(CouplingArgs a) {
   __shared__ float sh[32];
@@ -629,7 +635,7 @@ __global__ void add_slabs_kernel(const float* __restrict__ g, int ldg, const flo
     const long m = t / Ch; const int c = t % Ch;
     float v = g ? g[m * ldg + c] : 0.f;
     if (gext) v += gext[m * ldge + c];
-    for (int s = 0; s < S; ++s) v += slab[s * slab_stride + t];
+    v += slab_sum(slab, S, slab_stride, t);
     out[m * ldo + c] = v;
   }
 }
@@ -723,6 +729,9 @@ int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStre
 int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
                     int any_dense, hipStream_t st) {
   if (nsteps <= 0) return NFK_OK;
+  // C <= 192 covers every supported width: (192*192 + 192) / 256 = 145 chunks
+  hipLaunchKernelGGL(part_reduce_kernel, dim3(145, nsteps), dim3(256), 0, st, descs_dev, grads_dev);
+  NFK_LAUNCH_CHECK();
   hipLaunchKernelGGL(prep_bwd_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, grads_dev, gld, B);
   NFK_LAUNCH_CHECK();
   if (any_dense) {

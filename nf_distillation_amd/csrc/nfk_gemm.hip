@@ -654,7 +654,7 @@ int conv_splitk(int M, int N, int K, int epi) {
   int S = ceil_div(512, nMB);
   if (S > nk / 4) S = nk / 4;
   if (S < 1) S = 1;
-  if (S > 32) S = 32;
+  if (S > 16) S = 16;
   return S;
 }
 

@@ -351,7 +351,7 @@ int conv_splitk_bf16(int M, int N, int K, int epi) {
   int S = ceil_div(512, nMB);
   if (S > nk / 2) S = nk / 2;
   if (S < 1) S = 1;
-  if (S > 32) S = 32;
+  if (S > 16) S = 16;
   return S;
 }
 static bool big_tiles(int M, int N) { return (long)ceil_div(N, 128) * ceil_div(M, 128) >= 256; }
