@@ -210,9 +210,18 @@ int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const 
 enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW = 2, NFK_PROF_WGRAD_WIDE = 3,
        NFK_PROF_WGRAD_NARROW = 4, NFK_PROF_CLASSES = 5 };
 void nfk_profile_begin(void);
+/* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
+ * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */
+void nfk_set_aux_stream(void *stream);
 /* experiment knob for tools/gemm_bench.py: selects an alternative tile configuration (0 = default) */
 void nfk_set_tuning(int v);
 void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
+
+/* same, with the step count kept on the device (*step_dev = completed steps, incremented here), so the
+ * call sequence is identical every step and can be replayed from a captured hipGraph */
+int nfk_adam_step_dev(float *p, const float *g, float *m, float *v, size_t n, const float *sumsq, float clip,
+                      float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int *step_dev, void *stream);
 
 const char *nfk_version(void);
 

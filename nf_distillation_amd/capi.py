@@ -81,6 +81,7 @@ _PROTOS = {
     "nfk_version": (C.c_char_p, []),
     "nfk_profile_begin": (None, []),
     "nfk_set_tuning": (None, [i32]),
+    "nfk_set_aux_stream": (None, [vp]),
     "nfk_profile_end": (None, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
     "nfk_padded_k": (i32, [i32]),
@@ -118,6 +119,7 @@ _PROTOS = {
     "nfk_tab_bwd": (i32, [C.POINTER(TabStepC), C.POINTER(TabGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_sumsq": (i32, [vp, u64, vp, vp, vp]),
     "nfk_adam_step": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+    "nfk_adam_step_dev": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
 }
 
 _lib = None

@@ -60,7 +60,25 @@ int splitk_of(int bf16, int M, int N, int K) {
 }
 }  // namespace
 
+// Optional auxiliary stream: when set, the weight-gradient GEMMs of a step's backward run on it,
+// concurrently with the dgrad chain on the caller's stream (fork/join with events; capturable).
+static hipStream_t g_aux = nullptr;
+static hipEvent_t g_ev[4];
+static bool g_ev_ready = false;
+static void fork_to_aux(hipStream_t main_st, int i) {
+  (void)hipEventRecord(g_ev[i], main_st);
+  (void)hipStreamWaitEvent(g_aux, g_ev[i], 0);
+}
+
 extern "C" {
+
+void nfk_set_aux_stream(void* stream) {
+  g_aux = reinterpret_cast<hipStream_t>(stream);
+  if (g_aux && !g_ev_ready) {
+    for (auto& e : g_ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    g_ev_ready = true;
+  }
+}
 
 void nfk_set_tuning(int v) { set_tuning(v); }
 void nfk_profile_begin(void) { prof_begin(); }
@@ -229,36 +247,40 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   cb.es3 = s->es3; cb.ga3 = ga3; cb.gz = gz; cb.ldgz = C; cb.part = tail; cb.HW = HW; cb.C = C; cb.Cout = Cout;
   cb.additive = s->additive;
   NFK_TRY(launch_coupling_bwd(cb, B, st));
+  hipStream_t ws_st = st;  // stream of the wgrad GEMMs
+  if (g_aux && g_aux != st) { ws_st = g_aux; fork_to_aux(st, 0); }
 
   // conv3 (block.4): wgrad then dgrad
   WgradArgs w3{};
   w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
   w3.B = B; w3.H = H; w3.W = W; w3.out = wslab; w3.slab_stride = (long)Cout * 9 * hid;
   w3.qbf16 = bf;
-  NFK_TRY(bf ? wgrad_gemm_bf16(w3, L.S3w, st) : wgrad_gemm(w3, L.S3w, st));
-  NFK_TRY(wgrad_finalize(wslab, L.S3w, w3.slab_stride, Cout, hid, 9, g->g_w3, st));
+  NFK_TRY(bf ? wgrad_gemm_bf16(w3, L.S3w, ws_st) : wgrad_gemm(w3, L.S3w, ws_st));
+  NFK_TRY(wgrad_finalize(wslab, L.S3w, w3.slab_stride, Cout, hid, 9, g->g_w3, ws_st));
   ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD, bf, 1, bf);
   d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
   NFK_TRY(run_conv(bf, d3, st));
+  if (ws_st != st) fork_to_aux(st, 1);
 
   // conv2 (block.2)
   WgradArgs w2{};
   w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
   w2.B = B; w2.H = H; w2.W = W; w2.out = wslab; w2.slab_stride = (long)hid * hid;
   w2.pbf16 = bf; w2.qbf16 = bf;
-  NFK_TRY(bf ? wgrad_gemm_bf16(w2, L.S2w, st) : wgrad_gemm(w2, L.S2w, st));
-  NFK_TRY(wgrad_finalize(wslab, L.S2w, w2.slab_stride, hid, hid, 1, g->g_w2, st));
+  NFK_TRY(bf ? wgrad_gemm_bf16(w2, L.S2w, ws_st) : wgrad_gemm(w2, L.S2w, ws_st));
+  NFK_TRY(wgrad_finalize(wslab, L.S2w, w2.slab_stride, hid, hid, 1, g->g_w2, ws_st));
   ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
   d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
   NFK_TRY(run_conv(bf, d2, st));
+  if (ws_st != st) fork_to_aux(st, 2);
 
   // conv1 (block.0)
   WgradArgs w1{};
   w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = z; w1.ldq = C; w1.Cq = Ch; w1.taps = 9;
   w1.B = B; w1.H = H; w1.W = W; w1.out = wslab; w1.slab_stride = (long)hid * 9 * Ch;
   w1.pbf16 = bf;
-  NFK_TRY(bf ? wgrad_gemm_bf16(w1, L.S1w, st) : wgrad_gemm(w1, L.S1w, st));
-  NFK_TRY(wgrad_finalize(wslab, L.S1w, w1.slab_stride, hid, Ch, 9, g->g_w1, st));
+  NFK_TRY(bf ? wgrad_gemm_bf16(w1, L.S1w, ws_st) : wgrad_gemm(w1, L.S1w, ws_st));
+  NFK_TRY(wgrad_finalize(wslab, L.S1w, w1.slab_stride, hid, Ch, 9, g->g_w1, ws_st));
   ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
   NFK_TRY(run_conv(bf, d1a, st));
 
@@ -274,7 +296,12 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   m.x = gz; m.ldx = C; m.Wm = s->Wf; m.cv = nullptr; m.z = g_x; m.ldz = C; m.M = M; m.C = C; m.trans = 1;
   m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = L.S1; m.slab_stride = (long)M * Ch;
   m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
-  return launch_chanmix(m, st);
+  NFK_TRY(launch_chanmix(m, st));
+  if (ws_st != st) {  // join: this step's workspace and weight grads are complete when the call's stream moves on
+    (void)hipEventRecord(g_ev[3], ws_st);
+    (void)hipStreamWaitEvent(st, g_ev[3], 0);
+  }
+  return NFK_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -29,10 +29,21 @@ __global__ void __launch_bounds__(256) sumsq_stage2(const float* __restrict__ pa
   if (threadIdx.x == 0) out[0] += s;
 }
 
+__global__ void step_inc_kernel(int* step) { step[0] += 1; }
+
+// step_dev (optional): device-resident count of COMPLETED steps; when given, the bias corrections are
+// computed on the device from it (so the launch can be replayed from a hipGraph); lr_host is then the raw lr.
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, const float* __restrict__ sumsq,
                                                    float clip, float gscale, float step_size, float beta1,
-                                                   float beta2, float inv_sqrt_bc2, float eps, float wd) {
+                                                   float beta2, float inv_sqrt_bc2, float eps, float wd,
+                                                   const int* __restrict__ step_dev) {
+  if (step_dev) {
+    const int t = step_dev[0] + 1;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    step_size = (float)((double)step_size / bc1);
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  }
   float coef = gscale;
   if (sumsq && clip > 0.f) {
     const float norm = sqrtf(sumsq[0]) * gscale;
@@ -75,7 +86,22 @@ int nfk_adam_step(float* p, const float* g, float* m, float* v, size_t n, const 
   size_t want = (n + 255) / 256;
   const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, gscale,
-                     (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, weight_decay);
+                     (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, weight_decay,
+                     (const int*)nullptr);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* sumsq, float clip,
+                      float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int* step_dev, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!step_dev) return NFK_ERR_ARG;
+  size_t want = (n + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, gscale, lr, beta1,
+                     beta2, 1.f, eps, weight_decay, (const int*)step_dev);
+  NFK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

@@ -50,7 +50,9 @@ class FlowEngine:
         self.key = None
         self.is_1d = any(isinstance(l, M.FlowStep) and l.is_1d for l in layers)
         self._params = None
+        self._tensor_list = None
         self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
+        self.first_layer_hook = None  # callable(): first layer enqueued (input x may now be reused)
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -62,19 +64,21 @@ class FlowEngine:
             self._params = ps
         return self._params
 
+    def _tensors(self):
+        """Parameters and buffers of all layers (Parameter objects are stable; their .data may be re-homed)."""
+        if self._tensor_list is None:
+            ts = []
+            for l in self.layers:
+                ts.extend(l.parameters())
+                ts.extend(l.buffers())
+            self._tensor_list = ts
+        return self._tensor_list
+
     def _signature(self):
-        sig = []
-        for l in self.layers:
-            for t in list(l.parameters()) + list(l.buffers()):
-                sig.append(t.data_ptr())
-        return tuple(sig)
+        return tuple([t.data_ptr() for t in self._tensors()])
 
     def _version(self):
-        v = 0
-        for l in self.layers:
-            for t in list(l.parameters()) + list(l.buffers()):
-                v += t._version
-        return v
+        return sum([t._version for t in self._tensors()])
 
     def set_compute_dtype(self, name):
         """"f32" (parity mode, default) or "bf16" (bf16 operands, fp32 accumulate in the coupling-net convs)."""
@@ -449,6 +453,8 @@ class _EncodeFn(torch.autograd.Function):
                 ld = ld_out
             cur = out
             outs.append(out.permute(0, 3, 1, 2))
+            if r is st["recs"][0] and eng.first_layer_hook is not None:
+                eng.first_layer_hook()  # the model input has been consumed (and dequantised in place)
         ctx.saved = saved
         ctx.x_contig = x.is_contiguous()
         return tuple(outs) + (ld,)
@@ -510,7 +516,9 @@ class _EncodeFn(torch.autograd.Function):
                 nb = lib.nfk_chanmix_blocks(B * r.H * r.W, r.C)
                 part_off[r.idx] = (total, nb)
                 total += _a4(nb * (r.C * r.C + r.C))
-        parts = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
+        parts = st.get("parts")
+        if parts is None or parts.numel() < max(total, 4):
+            parts = st["parts"] = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
 
         g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
         for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):

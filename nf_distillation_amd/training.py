@@ -94,6 +94,8 @@ class FlatAdam:
         self.sumsq = torch.zeros(4, device=flat.data.device, dtype=torch.float32)
         self.partial = torch.zeros(1024, device=flat.data.device, dtype=torch.float32)
         self.t = 0
+        # completed-step counter on the device: every step issues the identical launch sequence (graph-replayable)
+        self.step_dev = torch.zeros(4, device=flat.data.device, dtype=torch.int32)
 
     def step(self, grad_scale=1.0):
         """grad_scale: e.g. 1/world_size after a sum all-reduce.  Returns nothing; the pre-clip global
@@ -104,9 +106,10 @@ class FlatAdam:
         self.sumsq.zero_()
         n = self.flat.numel
         check(lib.nfk_sumsq(ptr(self.flat.grad), n, ptr(self.partial), ptr(self.sumsq), s), "nfk_sumsq")
-        check(lib.nfk_adam_step(ptr(self.flat.data), ptr(self.flat.grad), ptr(self.m), ptr(self.v), n,
-                                ptr(self.sumsq), float(self.clip or 0.0), float(grad_scale), self.lr, self.betas[0],
-                                self.betas[1], self.eps, self.wd, self.t, s), "nfk_adam_step")
+        check(lib.nfk_adam_step_dev(ptr(self.flat.data), ptr(self.flat.grad), ptr(self.m), ptr(self.v), n,
+                                    ptr(self.sumsq), float(self.clip or 0.0), float(grad_scale), self.lr,
+                                    self.betas[0], self.betas[1], self.eps, self.wd, ptr(self.step_dev), s),
+              "nfk_adam_step_dev")
         eng = getattr(self.flat.model.flow, "_engine", None)
         if eng is not None:
             eng.mark_dirty()
@@ -133,15 +136,60 @@ class DistillationStep:
         self.opt = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay, clip_norm=clip_norm)
         self.reducer = GradAllReducer(self.flat.grad, process_group, bucket_bytes)
         self.world = self.reducer.world
+        self._side = self._aux = None
+        self._concurrent = False
         if self.world > 1:
             student.flow.engine().grad_hook = lambda idx: self.reducer.ready(self.flat.lo_for_layer(idx))
 
+    def enable_concurrency(self, on=True):
+        """Run the (frozen, no-grad) teacher forward on a side stream concurrently with the student forward, and
+        each FlowStep's weight-gradient GEMMs on an auxiliary stream concurrently with its dgrad chain.  The
+        launches are small (64-512 workgroups on 256 CUs), so independent branches fill otherwise idle CUs.
+        Results are bitwise unchanged: only the order in which independent kernels may run differs."""
+        if on and self._side is None:
+            self._side = torch.cuda.Stream()
+            self._aux = torch.cuda.Stream()
+        self._concurrent = bool(on)
+        capi.lib().nfk_set_aux_stream(self._aux.cuda_stream if on else None)
+
+    def _teacher_forward(self, x, noise_teacher):
+        with torch.no_grad():
+            t_z, _, _ = self.teacher(x, None, noise=noise_teacher)
+        return t_z
+
     def forward_losses(self, x, noise_student=None, noise_teacher=None):
-        s_z, s_nll, _ = self.student(x, None, noise=noise_student)
+        use_teacher = self.w_kd > 0 and self.teacher is not None
+        t_z = None
+        if use_teacher and self._concurrent:
+            # The teacher reads (and re-dequantises, in place) the SAME x right after the student's first kernel
+            # has consumed it (pl_module.py:216-225 order): fork there.
+            main = torch.cuda.current_stream()
+            box = {}
+            eng = self.student.flow.engine()
+
+            def fork():
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    box["t_z"] = self._teacher_forward(x, noise_teacher)
+                done = torch.cuda.Event()
+                done.record(self._side)
+                box["done"] = done
+
+            eng.first_layer_hook = fork
+            try:
+                s_z, s_nll, _ = self.student(x, None, noise=noise_student)
+            finally:
+                eng.first_layer_hook = None
+            main.wait_event(box["done"])
+            t_z = box["t_z"]
+        else:
+            s_z, s_nll, _ = self.student(x, None, noise=noise_student)
+            if use_teacher:
+                t_z = self._teacher_forward(x, noise_teacher)
         kd = None
-        if self.w_kd > 0 and self.teacher is not None:
-            with torch.no_grad():
-                t_z, _, _ = self.teacher(x, None, noise=noise_teacher)
+        if use_teacher:
             for si, ti in zip(self.s_idx, self.t_idx):
                 d = (s_z[si] - t_z[ti]).square().flatten(1).mean(1)
                 kd = d if kd is None else kd + d
@@ -160,3 +208,62 @@ class DistillationStep:
         self.reducer.finish()
         self.opt.step(grad_scale=1.0 / self.world)
         return {k: v.detach() for k, v in out.items()}
+
+
+class CapturedStep:
+    """The whole training_step (student fwd, teacher fwd, losses, backward, clip, Adam) as ONE hipGraph.
+
+    A step issues several hundred small launches; enqueueing them from Python costs as much host time as
+    the GPU needs to run them.  After `warmup` eager steps (which also fix every lazily built descriptor and
+    kernel attribute), the step is captured once with torch.cuda.graph and then replayed: the host only
+    copies the batch into a static buffer and calls hipGraphLaunch.  Falls back to eager execution if capture
+    is not possible (e.g. multi-rank runs keep the RCCL all-reduce outside the graph: see `training_step`).
+    """
+
+    def __init__(self, step, example_x, warmup=2, with_noise=False):
+        self.step = step
+        self.static_x = example_x.clone()
+        # optional caller-supplied dequantisation noise (parity tests); otherwise drawn on the device inside the graph
+        self.static_ns = torch.zeros_like(example_x) if with_noise else None
+        self.static_nt = torch.zeros_like(example_x) if with_noise else None
+        self.graph = None
+        self.out = None
+        self.enabled = True
+        self._warm = warmup
+
+    def _body(self):
+        return self.step.training_step(self.static_x, self.static_ns, self.static_nt)
+
+    def prepare(self):
+        """Run the eager warm-up steps and capture now (so that no timed step pays for it)."""
+        while self.enabled and self.graph is None and self.step.world == 1:
+            self.training_step(self.static_x.clone(), *([self.static_ns, self.static_nt] if self.static_ns is not None else []))
+
+    def training_step(self, x, noise_student=None, noise_teacher=None):
+        if not self.enabled or self.step.world > 1:
+            return self.step.training_step(x, noise_student, noise_teacher)
+        self.static_x.copy_(x)
+        if self.static_ns is not None:
+            self.static_ns.copy_(noise_student)
+            self.static_nt.copy_(noise_teacher)
+        if self.graph is None:
+            if self._warm > 0:
+                self._warm -= 1
+                return self._body()
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = self._body()
+                self.graph = g
+                # the capture itself does not execute: run the step it describes
+                self.graph.replay()
+                return self.out
+            except Exception as exc:  # pragma: no cover - depends on the runtime
+                import warnings
+                warnings.warn(f"hipGraph capture failed ({exc!r}); running eagerly")
+                self.enabled = False
+                torch.cuda.synchronize()
+                return self.step.training_step(x, noise_student, noise_teacher)
+        self.graph.replay()
+        return self.out
