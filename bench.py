@@ -124,7 +124,7 @@ def main():
 
     # one hipGraph for the whole step (fwd + bwd + clip + Adam); the host only copies the batch in and replays
     runner = step
-    if world == 1 and not args.no_graph:
+    if not args.no_graph:
         from nf_distillation_amd.training import CapturedStep
         runner = CapturedStep(step, data[0])
         runner.prepare()  # eager warm-up + capture, before the W warm-up steps

@@ -138,8 +138,7 @@ class DistillationStep:
         self.world = self.reducer.world
         self._side = self._aux = None
         self._concurrent = False
-        if self.world > 1:
-            student.flow.engine().grad_hook = lambda idx: self.reducer.ready(self.flat.lo_for_layer(idx))
+        self.set_allreduce_overlap(True)
 
     def enable_concurrency(self, on=True):
         """Run the (frozen, no-grad) teacher forward on a side stream concurrently with the student forward, and
@@ -199,25 +198,45 @@ class DistillationStep:
         result = (self.w_nll * s_nll + self.w_kd * kd).mean()
         return {"nll": s_nll.mean(), "kd": kd.mean(), "result_loss": result}
 
-    def training_step(self, x, noise_student=None, noise_teacher=None):
-        """x: [B_local, C, H, W] on the GPU (mutated in place by the dequantisation noise, as upstream)."""
+    # A step = three phases; multi-rank graph replay captures the first and the last separately so that the
+    # collective itself is never part of a captured graph.
+    def fwd_bwd(self, x, noise_student=None, noise_teacher=None):
         self.flat.zero_grad()
         self.reducer.reset()
         out = self.forward_losses(x, noise_student, noise_teacher)
         out["result_loss"].backward()
-        self.reducer.finish()
-        self.opt.step(grad_scale=1.0 / self.world)
         return {k: v.detach() for k, v in out.items()}
+
+    def allreduce(self):
+        self.reducer.finish()   # launches whatever the backward hooks have not launched yet, then waits
+
+    def optimize(self):
+        self.opt.step(grad_scale=1.0 / self.world)
+
+    def set_allreduce_overlap(self, on):
+        """on: buckets are all-reduced from inside the backward (eager mode); off: once, after it (graph mode)."""
+        eng = self.student.flow.engine()
+        eng.grad_hook = (lambda idx: self.reducer.ready(self.flat.lo_for_layer(idx))) if (on and self.world > 1) else None
+
+    def training_step(self, x, noise_student=None, noise_teacher=None):
+        """x: [B_local, C, H, W] on the GPU (mutated in place by the dequantisation noise, as upstream)."""
+        out = self.fwd_bwd(x, noise_student, noise_teacher)
+        self.allreduce()
+        self.optimize()
+        return out
 
 
 class CapturedStep:
-    """The whole training_step (student fwd, teacher fwd, losses, backward, clip, Adam) as ONE hipGraph.
+    """The training_step replayed from hipGraphs instead of being enqueued launch by launch from Python.
 
-    A step issues several hundred small launches; enqueueing them from Python costs as much host time as
-    the GPU needs to run them.  After `warmup` eager steps (which also fix every lazily built descriptor and
-    kernel attribute), the step is captured once with torch.cuda.graph and then replayed: the host only
-    copies the batch into a static buffer and calls hipGraphLaunch.  Falls back to eager execution if capture
-    is not possible (e.g. multi-rank runs keep the RCCL all-reduce outside the graph: see `training_step`).
+    A step issues several hundred small launches; enqueueing them from the host costs as much time as the GPU
+    needs to run them.  After `warmup` eager steps (which also fix every lazily built descriptor and kernel
+    attribute) the step is captured with torch.cuda.graph and then replayed; the host only copies the batch
+    into a static buffer and calls hipGraphLaunch.
+      * one rank : ONE graph = zero-grad + student fwd + teacher fwd + losses + backward + clip + Adam
+      * N ranks  : graph A (zero-grad .. backward)  ->  eager bucketed RCCL all-reduce of the flat gradient
+                   arena  ->  graph B (clip + Adam).  No collective is ever captured.
+    Falls back to eager execution if capture fails.
     """
 
     def __init__(self, step, example_x, warmup=2, with_noise=False):
@@ -226,21 +245,47 @@ class CapturedStep:
         # optional caller-supplied dequantisation noise (parity tests); otherwise drawn on the device inside the graph
         self.static_ns = torch.zeros_like(example_x) if with_noise else None
         self.static_nt = torch.zeros_like(example_x) if with_noise else None
-        self.graph = None
+        self.graph = self.graph_b = None
         self.out = None
         self.enabled = True
         self._warm = warmup
-
-    def _body(self):
-        return self.step.training_step(self.static_x, self.static_ns, self.static_nt)
+        self.split = step.world > 1
+        if self.split:
+            step.set_allreduce_overlap(False)
 
     def prepare(self):
         """Run the eager warm-up steps and capture now (so that no timed step pays for it)."""
-        while self.enabled and self.graph is None and self.step.world == 1:
+        while self.enabled and self.graph is None:
             self.training_step(self.static_x.clone(), *([self.static_ns, self.static_nt] if self.static_ns is not None else []))
 
+    def _eager(self):
+        return self.step.training_step(self.static_x, self.static_ns, self.static_nt)
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        if not self.split:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.out = self._eager()
+            self.graph = g
+            return
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self.out = self.step.fwd_bwd(self.static_x, self.static_ns, self.static_nt)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self.step.optimize()
+        self.graph, self.graph_b = ga, gb
+
+    def _replay(self):
+        self.graph.replay()
+        if self.split:
+            self.step.reducer.reset()
+            self.step.allreduce()
+            self.graph_b.replay()
+        return self.out
+
     def training_step(self, x, noise_student=None, noise_teacher=None):
-        if not self.enabled or self.step.world > 1:
+        if not self.enabled:
             return self.step.training_step(x, noise_student, noise_teacher)
         self.static_x.copy_(x)
         if self.static_ns is not None:
@@ -249,21 +294,17 @@ class CapturedStep:
         if self.graph is None:
             if self._warm > 0:
                 self._warm -= 1
-                return self._body()
+                return self._eager()
             try:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.out = self._body()
-                self.graph = g
-                # the capture itself does not execute: run the step it describes
-                self.graph.replay()
-                return self.out
+                self._capture()
+                return self._replay()   # capturing does not execute: run the step it describes
             except Exception as exc:  # pragma: no cover - depends on the runtime
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({exc!r}); running eagerly")
                 self.enabled = False
+                self.graph = self.graph_b = None
+                if self.split:
+                    self.step.set_allreduce_overlap(True)
                 torch.cuda.synchronize()
                 return self.step.training_step(x, noise_student, noise_teacher)
-        self.graph.replay()
-        return self.out
+        return self._replay()
