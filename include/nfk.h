@@ -171,6 +171,18 @@ int nfk_step2d_inv(const nfk_step2d *s, const float *y, int ldy, const float *ld
 int nfk_step2d_bwd(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
                    const float *h1, const float *h2, const float *hsave, const float *g_out,
                    const float *g_ext, const float *g_ld, float *g_x, float *ws, void *stream);
+/* Fused forward of one FlowStep in ONE launch (bf16 mode, 64-pixel row tiles; see csrc/nfk_fused.hip).
+ * nfk_step2d_fused_tiles: 0 if this step's geometry is not supported (use nfk_step2d_fwd), else the number of
+ * log-det partial slots per sample.  zsave/h1save/h2save/hsave as in nfk_step2d_fwd (NULL when no backward
+ * follows; h1save/h2save are bf16 [M][hidden]).  The per-sample log-det is NOT updated here: the step writes
+ * ldpart[B][tiles] and nfk_ld_finish adds the partials of a run of steps to ld_in in fixed order. */
+int nfk_step2d_fused_tiles(const nfk_step2d *s);
+/* diagnostic: device buffer [workgroups][8] of shader-clock stamps per phase of the fused kernel (NULL = off) */
+void nfk_fused_set_stamps(void *buf);
+void nfk_fused_set_debug(int bits); /* diagnostic bisect of the fused kernel (results become wrong); 0 = off */
+int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zsave, void *h1save, void *h2save,
+                         float *hsave, float *zout, float *ldpart, void *stream);
+int nfk_ld_finish(const float *ld_in, const float *ldpart, int nsteps, int B, int tiles, float *ld_out, void *stream);
 /* Split2d.forward / reverse / backward */
 int nfk_split2d_fwd(const nfk_split2d *s, const float *x, const float *ld_in, float *z1out, float *hsave,
                     float *ws, float *ld_out, void *stream);

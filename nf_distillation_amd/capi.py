@@ -109,6 +109,11 @@ _PROTOS = {
     "nfk_step2d_inv": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_step2d_bwd": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp,
                              vp, vp]),
+    "nfk_step2d_fused_tiles": (i32, [C.POINTER(Step2d)]),
+    "nfk_fused_set_stamps": (None, [vp]),
+    "nfk_fused_set_debug": (None, [i32]),
+    "nfk_step2d_fwd_fused": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_ld_finish": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nfk_split2d_fwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp]),
     "nfk_split2d_inv": (i32, [C.POINTER(Split2d), vp, vp, f32, vp, vp, vp]),
     "nfk_split2d_bwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -53,6 +53,7 @@ class FlowEngine:
         self._tensor_list = None
         self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
         self.first_layer_hook = None  # callable(): first layer enqueued (input x may now be reused)
+        self.fused = True      # bf16 mode: one fused launch per FlowStep forward where the geometry allows
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -156,7 +157,9 @@ class FlowEngine:
 
         prep_buf = torch.zeros(max(prep_floats, 4), dtype=torch.float32, device=device)
         pack_buf = torch.zeros(max(pack_floats, 4), dtype=torch.float32, device=device)
-        step_buf = torch.zeros(max(step_pack, 8), dtype=torch.bfloat16 if self.bf16 else torch.float32, device=device)
+        # +1024: the fused kernel's padded conv1 k-steps may read up to 512 B past a weight row (against zero columns)
+        step_buf = torch.zeros(max(step_pack, 8) + 1024, dtype=torch.bfloat16 if self.bf16 else torch.float32,
+                               device=device)
         pb, kb, sb, esz = prep_buf.data_ptr(), pack_buf.data_ptr(), step_buf.data_ptr(), (2 if self.bf16 else 4)
         step_repack = []
         keep = []  # tensors that must stay alive (perm indices, zero vectors)
@@ -402,6 +405,7 @@ class _EncodeFn(torch.autograd.Function):
 
         scratch = _Scratch(st, dev)
         cur, cur_ld = None, None  # NHWC tensor of the running activation
+        run, keep_alive = None, []
         for r in st["recs"]:
             if r.kind == "squeeze":
                 out = torch.empty((B, r.H // 2, r.W // 2, 4 * r.C), device=dev, dtype=torch.float32)
@@ -416,6 +420,42 @@ class _EncodeFn(torch.autograd.Function):
                 else:
                     check(lib.nfk_squeeze(ptr(cur), r.C, None, ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_squeeze")
                 saved.append(None)
+            elif r.kind == "step" and eng.fused and eng.bf16 and lib.nfk_step2d_fused_tiles(C.byref(r.cs)) > 0:
+                # ---- fused path: one launch per step; the log-det is accumulated once per run of steps
+                if cur is None:
+                    cur = _nhwc(x)
+                tiles = lib.nfk_step2d_fused_tiles(C.byref(r.cs))
+                if run is None:
+                    n_run = 0
+                    for r2 in st["recs"][r.idx:]:
+                        if r2.kind != "step" or (r2.C, r2.H, r2.W) != (r.C, r.H, r.W):
+                            break
+                        n_run += 1
+                    run = {"buf": torch.empty(n_run * B * tiles, device=dev, dtype=torch.float32), "k": 0, "n": n_run,
+                           "tiles": tiles}
+                M_ = B * r.H * r.W
+                out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                zb = h1 = h2 = hs = None
+                if need:
+                    arena = torch.empty(_a4(M_ * r.C) + 2 * _a4(M_ * r.hid) + _a4(M_ * r.Cout), device=dev,
+                                        dtype=torch.float32)
+                    o1 = _a4(M_ * r.C)
+                    o2 = o1 + _a4(M_ * r.hid)
+                    o3 = o2 + _a4(M_ * r.hid)
+                    zb, h1, h2, hs = arena[:o1], arena[o1:o2], arena[o2:o3], arena[o3:]
+                    saved.append((cur, zb, h1, h2, hs, arena))
+                else:
+                    saved.append(None)
+                part = run["buf"].data_ptr() + 4 * run["k"] * B * tiles
+                check(lib.nfk_step2d_fwd_fused(C.byref(r.cs), ptr(cur), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs), ptr(out),
+                                               part, s), "nfk_step2d_fwd_fused")
+                run["k"] += 1
+                if run["k"] == run["n"]:
+                    ld_out = torch.empty_like(ld)
+                    check(lib.nfk_ld_finish(ptr(ld), ptr(run["buf"]), run["n"], B, tiles, ptr(ld_out), s), "nfk_ld_finish")
+                    ld = ld_out
+                    keep_alive.append(run["buf"])
+                    run = None
             elif r.kind == "step":
                 if cur is None:
                     cur = _nhwc(x)

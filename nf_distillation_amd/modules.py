@@ -447,6 +447,11 @@ class Glow(nn.Module):
         self.flow.engine().set_compute_dtype(name)
         return self
 
+    def set_fused(self, on=True):
+        """bf16 mode only: run each FlowStep forward as one fused launch (default) or as five kernels."""
+        self.flow.engine().fused = bool(on)
+        return self
+
     def set_actnorm_init(self):
         for _, module in self.named_modules():
             if isinstance(module, (ActNorm2d, ActNorm1d)):

@@ -79,3 +79,37 @@ def test_distillation_step_trains():
     for _ in range(20):
         out = step.training_step(x0.clone().cuda(), torch.zeros_like(x0).cuda(), torch.zeros_like(x0).cuda())
     assert float(out["result_loss"]) < first
+
+
+@pytest.mark.parametrize("name", ["cifar_k8_full", "glow32"])
+def test_fused_step_equals_unfused(name):
+    """The one-launch FlowStep forward (csrc/nfk_fused.hip) against the five-kernel bf16 path: same bf16 roundings
+    of h1/h2/weights, so outputs agree to fp32 summation-order noise; gradients (same backward) likewise."""
+    g = Golden(name)
+    cfg = g.cfg
+    if name.endswith("_full"):
+        sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+        h, w, c = cfg["image_shape"]
+        x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 5)
+    else:
+        sd, x, noise = g.group("sd"), g.t("x"), g.t("noise")
+    res = []
+    for fused in (True, False):
+        model = build(cfg, sd).set_fused(fused)
+        outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
+        bpd.mean().backward()
+        torch.cuda.synchronize()
+        res.append(([o.detach().cpu() for o in outs], bpd.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters()}))
+    (o1, b1, g1), (o0, b0, g0) = res
+    assert rel_err(b1, b0) < 2e-5, rel_err(b1, b0)
+    for i, (a, b) in enumerate(zip(o1, o0)):
+        assert rel_err(a, b) < 2e-3, (i, rel_err(a, b))
+    # the two forwards round h1/h2 identically but sum in different orders, so a few ReLU masks / bf16 roundings
+    # flip; gradients of a 29-layer chain then differ by a few % on individual tensors but point the same way
+    num = da = db = 0.0
+    for k in g0:
+        a_, b_ = g1[k].double().flatten(), g0[k].double().flatten()
+        num, da, db = num + float(a_ @ b_), da + float(a_ @ a_), db + float(b_ @ b_)
+        if float(g0[k].abs().max()) > 0:
+            assert rel_err(g1[k], g0[k]) < 0.1, (k, rel_err(g1[k], g0[k]))
+    assert num / (da ** 0.5 * db ** 0.5) > 0.9995
