@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) prep_bwd_dense_kernel(const PrepDesc* __r
 // ==========================================================================================
 // chanmix:  z[m][o] = sum_c Wm[o][c] x[m][c] + cv[o]      (trans: uses Wm[c][o], no cv)
 // ==========================================================================================
-constexpr int CM_MAX_BLOCKS = 64;  // backward: at most this many partial (gWf, gcf) slabs per step
+constexpr int CM_MAX_BLOCKS = 256;  // backward: at most this many partial (gWf, gcf) slabs per step
 
 // pixels per tile: TP * ceil(C/4) output-groups ~ 256 threads
 static inline __host__ __device__ int cm_tile_pixels(int C) {

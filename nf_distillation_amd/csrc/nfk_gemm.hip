@@ -524,9 +524,7 @@ __global__ void wgrad_finalize_kernel(const float* __restrict__ slabs, int S, lo
     const long r = t / taps;
     const int ci = r % Cin, co = r / Cin;
     const long src = (long)co * J + tap * Cin + ci;
-    float s = 0.f;
-    for (int i = 0; i < S; ++i) s += slabs[i * slab_stride + src];
-    gradW[t] += s;
+    gradW[t] += slab_sum(slabs, S, slab_stride, src);
   }
 }
 
