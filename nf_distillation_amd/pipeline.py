@@ -1,0 +1,136 @@
+"""Software-pipelined distillation step: teacher(t+1) runs concurrently with student(t).
+
+In the reference's step (pl_module.py:198-382) the critical path is
+    teacher forward  ->  loss  ->  student backward  ->  optimiser,
+but the teacher is frozen: its outputs depend only on the batch.  `PipelinedStep` therefore computes the
+teacher's hint tensors for batch t+1 on a side stream while the student runs forward / backward / Adam on
+batch t with the hints produced one call earlier.  Every step still performs exactly the work of the
+reference step, on the same values:
+
+  * batch t+1 is dequantised for the student (x += n_s) and that tensor is kept for the next call, then the
+    teacher re-dequantises the same buffer in place (x += n_t), so the teacher still sees student noise +
+    its own (models/utils.py:38 + pl_module.py:216-225) and the RNG draws come in the reference's order
+    n_s(0), n_t(0), n_s(1), n_t(1), ...
+  * the student consumes the hint tensors through static buffers, so the whole call (both branches) can be
+    captured into one hipGraph and replayed.
+
+`training_step(x_next)` trains on the batch given to the PREVIOUS call and returns its losses; `prime(x0)`
+starts the pipeline and `drain()` trains on the last batch.  Results are bit-identical to the sequential
+`DistillationStep` fed with the same noise (tests/test_gpu_training.py).
+"""
+import torch
+
+from .training import DistillationStep
+
+
+class PipelinedStep:
+    def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2):
+        if step.teacher is None or step.w_kd <= 0:
+            raise ValueError("pipelining needs a teacher with kd_weight > 0")
+        self.step = step
+        dev = example_x.device
+        self.x_in = torch.empty_like(example_x)        # incoming batch t+1
+        self.x_stu_next = torch.empty_like(example_x)  # batch t+1 + student noise (student input of the next call)
+        self.x_cur = torch.empty_like(example_x)       # student input of this call
+        self.zeros = torch.zeros_like(example_x)       # "noise" for the already dequantised student input
+        self.t_next = None   # static hint buffers written by the teacher branch
+        self.t_cur = None    # ... and read by the student branch
+        self.side = torch.cuda.Stream()
+        self.use_graph = use_graph and step.world == 1
+        self.graph, self.out, self._warm = None, None, warmup
+        self.primed = False
+
+    # ------------------------------------------------------------------ the two branches
+    def _teacher_branch(self):
+        """dequantise x_in for the student, keep that copy, run the teacher on the same buffer, keep its hints"""
+        st = self.step
+        self.x_in.add_(torch.empty_like(self.x_in).uniform_(0, 1.0 / 256))   # n_s(t+1)
+        self.x_stu_next.copy_(self.x_in)
+        with torch.no_grad():
+            t_z, _, _ = st.teacher(self.x_in, None)                            # adds n_t(t+1) in place
+        hints = [t_z[i] for i in st.t_idx]
+        if self.t_next is None:
+            self.t_next = [torch.empty_like(h) for h in hints]
+            self.t_cur = [torch.empty_like(h) for h in hints]
+        for dst, h in zip(self.t_next, hints):
+            dst.copy_(h)
+
+    def _student_branch(self):
+        st = self.step
+        st.flat.zero_grad()
+        st.reducer.reset()
+        s_z, s_nll, _ = st.student(self.x_cur, None, noise=self.zeros)
+        kd = None
+        for si, tz in zip(st.s_idx, self.t_cur):
+            d = (s_z[si] - tz).square().flatten(1).mean(1)
+            kd = d if kd is None else kd + d
+        kd = kd / max(len(st.s_idx), 1)
+        result = (st.w_nll * s_nll + st.w_kd * kd).mean()
+        result.backward()
+        st.allreduce()
+        st.optimize()
+        return {"nll": s_nll.mean().detach(), "kd": kd.mean().detach(), "result_loss": result.detach()}
+
+    def _body(self):
+        main = torch.cuda.current_stream()
+        # hand over what the previous call prepared
+        for dst, src in zip(self.t_cur, self.t_next):
+            dst.copy_(src)
+        self.x_cur.copy_(self.x_stu_next)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self.side.wait_event(fork)
+        with torch.cuda.stream(self.side):
+            self._teacher_branch()
+            join = torch.cuda.Event()
+            join.record(self.side)
+        out = self._student_branch()
+        main.wait_event(join)
+        return out
+
+    # ------------------------------------------------------------------ public API
+    def prime(self, x0):
+        """Start the pipeline with the first batch (runs one teacher forward)."""
+        self.x_in.copy_(x0)
+        self._teacher_branch()
+        self.primed = True
+
+    def training_step(self, x_next):
+        """Train on the previously supplied batch while the teacher processes `x_next`."""
+        if not self.primed:
+            raise RuntimeError("call prime(first_batch) first")
+        self.x_in.copy_(x_next)
+        if not self.use_graph:
+            return self._body()
+        if self.graph is None:
+            if self._warm > 0:
+                self._warm -= 1
+                return self._body()
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = self._body()
+                self.graph = g
+            except Exception as exc:  # pragma: no cover - depends on the runtime
+                import warnings
+                warnings.warn(f"hipGraph capture of the pipelined step failed ({exc!r}); running eagerly")
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return self._body()
+        self.graph.replay()
+        return self.out
+
+    def prepare(self, x0):
+        """prime + eager warm-up + capture, so that no timed call pays for it (consumes warm-up batches = x0)."""
+        self.prime(x0)
+        while self.use_graph and self.graph is None:
+            self.training_step(x0)
+
+    def drain(self):
+        """Train on the last supplied batch (no new teacher work)."""
+        for dst, src in zip(self.t_cur, self.t_next):
+            dst.copy_(src)
+        self.x_cur.copy_(self.x_stu_next)
+        self.primed = False
+        return self._student_branch()
