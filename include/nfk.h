@@ -66,6 +66,9 @@ typedef struct nfk_step2d {
   const float *Wf, *cf, *Wi, *ci, *dld, *es1, *es2, *es3; /* from nfk_prep */
   const float *wt1, *wt2, *wt3;     /* repacked forward weights [N][Kp]  (nfk_repack) */
   const float *wd1, *wd2, *wd3;     /* repacked dgrad weights            (nfk_repack) */
+  /* bf16 mode, optional (NULL = absent): the forward weights once more in MFMA-fragment order, so that a wave
+   * fetches every A operand as 1 KiB of contiguous bytes (nfk_repack_desc.wf; used by nfk_step2d_fwd_fused) */
+  const void *wf1, *wf2, *wf3;
 } nfk_step2d;
 
 typedef struct nfk_step2d_grads {   /* all accumulate (+=) */
@@ -99,7 +102,10 @@ typedef struct nfk_tab_grads { /* accumulate (+=) */
 typedef struct nfk_repack_desc {
   const float *w;
   float *wt, *wd; /* wd may be NULL */
-  int32_t Cout, Cin, taps, pad_;
+  int32_t Cout, Cin, taps;
+  int32_t frag;   /* layout of wf: 1 = 32x32x16 A fragments [Cout/32][Kp/16][64 lanes][8], Cout % 32 == 0;
+                   *               2 = 16x16x32 A fragments [ceil(Cout/16)][Kp/32][64 lanes][8], zero rows behind Cout */
+  void *wf;       /* bf16 repack only, may be NULL: fragment-ordered copy of wt (Kp = nfk_padded_k_bf16(taps*Cin)) */
 } nfk_repack_desc;
 
 typedef struct nfk_small_grad_args {
@@ -220,7 +226,9 @@ int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const 
  * milliseconds, launches, algorithmic FLOPs (2*M*N*K) and algorithmic bytes.  Arrays of
  * NFK_PROF_CLASSES. */
 enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW = 2, NFK_PROF_WGRAD_WIDE = 3,
-       NFK_PROF_WGRAD_NARROW = 4, NFK_PROF_CLASSES = 5 };
+       NFK_PROF_WGRAD_NARROW = 4,
+       NFK_PROF_FUSED_STEP = 5, /* nfk_step2d_fwd_fused: flops of the three convs, bytes = x + z + weights (+ saves) */
+       NFK_PROF_CLASSES = 6 };
 void nfk_profile_begin(void);
 /* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
  * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */

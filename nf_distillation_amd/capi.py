@@ -46,7 +46,8 @@ class Step2d(C.Structure):
                 ("b1", c_fp), ("b2", c_fp), ("bias3", c_fp),
                 ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp),
                 ("es1", c_fp), ("es2", c_fp), ("es3", c_fp),
-                ("wt1", c_fp), ("wt2", c_fp), ("wt3", c_fp), ("wd1", c_fp), ("wd2", c_fp), ("wd3", c_fp)]
+                ("wt1", c_fp), ("wt2", c_fp), ("wt3", c_fp), ("wd1", c_fp), ("wd2", c_fp), ("wd3", c_fp),
+                ("wf1", c_fp), ("wf2", c_fp), ("wf3", c_fp)]
 
 
 class Step2dGrads(C.Structure):
@@ -72,7 +73,7 @@ class TabGrads(C.Structure):
 
 class RepackDesc(C.Structure):
     _fields_ = [("w", c_fp), ("wt", c_fp), ("wd", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
-                ("taps", C.c_int32), ("pad_", C.c_int32)]
+                ("taps", C.c_int32), ("frag", C.c_int32), ("wf", c_fp)]
 
 
 i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long
@@ -147,7 +148,8 @@ def lib():
 
 
 PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
-                "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>")
+                "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>",
+                "fused_step_fwd_kernel (whole FlowStep forward)")
 
 
 def profile_begin():

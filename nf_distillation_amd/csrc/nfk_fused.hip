@@ -33,7 +33,7 @@ struct FusedArgs {
   float* zout;           // [M][C]
   float* ldpart;         // [B][tps] partial log-det of this step
   int R, TS, halo;       // rows per tile, samples per tile, 1 if the tile needs halo rows
-  unsigned long long* stamps;  // diagnostic: [grid][8] cycle stamps (null in production)
+  unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
   int dbg;                     // diagnostic bisect bits (0 in production)
 };
 
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) fused_step_fwd_kernel(FusedArgs a) {
   const int row0 = (TS == 1) ? (blockIdx.x % tps) * R : 0;
   const int zh = 2 * halo;  // halo rows of the Zm region
   auto stamp = [&](int i) {
-    if (a.stamps && tid == 0) a.stamps[(long)blockIdx.x * 8 + i] = __builtin_readcyclecounter();
+    if (a.stamps && tid == 0) a.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
   };
   stamp(0);
 
@@ -473,6 +473,11 @@ __global__ void ld_finish_kernel(const float* __restrict__ ld_in, const float* _
 static unsigned long long* g_stamps = nullptr;
 static int g_dbg = 0;
 static int g_force_fused = 0;
+static int g_no_v2 = 0;
+static int grid_of(const nfk_step2d& s) {   // 64 output pixels per workgroup
+  const int HW = s.H * s.W;
+  return HW <= 64 ? (s.B * HW + 63) / 64 : s.B * (HW / 64);
+}
 static bool fused_pick(const nfk_step2d& s, int* R, int* TS, int* halo) {
   if (!s.bf16 || s.hidden != 512 || s.Cout > 48 || (s.C & 3) != 0) return false;
   const int HW = s.H * s.W;
@@ -529,16 +534,53 @@ using namespace nfk;
 extern "C" {
 
 void nfk_fused_set_stamps(void* buf) { g_stamps = reinterpret_cast<unsigned long long*>(buf); }
-void nfk_fused_set_debug(int bits) { g_dbg = bits & 0xff; g_force_fused = (bits >> 8) & 1; }
+void nfk_fused_set_debug(int bits) {
+  g_dbg = bits & 0xff; g_force_fused = (bits >> 8) & 1; g_no_v2 = (bits >> 9) & 1;
+}
+
+static int v2_tiles(const nfk_step2d& s) {
+  if (g_no_v2 || !s.bf16) return 0;
+  // measured (CIFAR, B=64, teacher K=32): generation 2 beats the five-kernel path at every level, also where it
+  // fills only 64 / 16 CUs (38 / 37 / 49 us per step against 76 / 50 / 54)
+  return fused2_tiles(s);
+}
 
 int nfk_step2d_fused_tiles(const nfk_step2d* s) {
+  if (const int t2 = v2_tiles(*s)) return t2;
   int R, TS, halo;
   if (!fused_pick(*s, &R, &TS, &halo)) return 0;
   return TS == 1 ? s->H / R : 1;   // log-det partial slots per sample
 }
 
+static int step2d_fwd_fused_impl(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save,
+                                 void* h2save, float* hsave, float* zout, float* ldpart, void* stream);
+
 int nfk_step2d_fwd_fused(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save, void* h2save,
                          float* hsave, float* zout, float* ldpart, void* stream) {
+  // algorithmic work of one FlowStep forward (bench.py roofline leg): the three convs' FLOPs; HBM bytes = the step's
+  // input and output, its bf16 weights once, and what a training forward keeps for the backward
+  const double M = (double)s->B * s->H * s->W, hid = s->hidden, K1 = 9.0 * (s->C / 2);
+  const double flops = 2.0 * M * (K1 * hid + hid * hid + 9.0 * hid * s->Cout);
+  double bytes = 8.0 * M * s->C + 2.0 * (K1 * hid + hid * hid + 9.0 * hid * s->Cout);
+  if (zsave) bytes += 4.0 * M * s->C;
+  if (h1save) bytes += 2.0 * M * hid;
+  if (h2save) bytes += 2.0 * M * hid;
+  if (hsave) bytes += 4.0 * M * s->Cout;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  prof_scope_begin(NFK_PROF_FUSED_STEP, flops, bytes, st);
+  const int rc = step2d_fwd_fused_impl(s, x, ldx, zsave, h1save, h2save, hsave, zout, ldpart, stream);
+  prof_scope_end(NFK_PROF_FUSED_STEP, st);
+  return rc;
+}
+
+static int step2d_fwd_fused_impl(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save,
+                                 void* h2save, float* hsave, float* zout, float* ldpart, void* stream) {
+  if (v2_tiles(*s)) {
+    FusedCall c{};
+    c.s = *s; c.x = x; c.ldx = ldx; c.zsave = zsave; c.h1save = h1save; c.h2save = h2save; c.hsave = hsave;
+    c.zout = zout; c.ldpart = ldpart; c.stamps = g_stamps; c.dbg = g_dbg;
+    return fused2_launch(c, reinterpret_cast<hipStream_t>(stream));
+  }
   FusedArgs a{};
   if (!fused_pick(*s, &a.R, &a.TS, &a.halo)) return NFK_ERR_ARG;
   a.s = *s; a.x = x; a.ldx = ldx; a.zsave = zsave;

@@ -1,0 +1,611 @@
+// nfk fused FlowStep forward, second generation (bf16 operands / fp32 accumulate): ONE launch per FlowStep
+// (models/flows.py:142-171: ActNorm -> invertible 1x1 conv -> affine/additive coupling with the 3-conv net
+// models/flows.py:17-60).
+//
+//   workgroup = a spatial tile of 64 output pixels (whole image rows, +1 halo row each side when the tile is not
+//   a whole image): CIFAR level 1: 4 rows of one image, level 2: one 8x8 image, level 3: four 4x4 images.
+//   1. mix      z = Wf x + cf on the tile rows (+2 halo rows)                              -> LDS (fp32)
+//   2. im2col   3x3 taps of z1 on the h-region (tile + 1 halo row)                          -> LDS (bf16)
+//   3. conv1    3x3 C/2->512, ActNorm, ReLU.  32x32x16 MFMA: every wave owns 4 tiles of 32 output channels and
+//               keeps their W1 rows in registers from the start of the kernel               -> h1 in LDS (bf16)
+//   4. conv2    1x1 512->512 in 4 chunks of 128 channels (32 per wave).  A fragments (W2 rows) stream from L2
+//               through a two-half register ring, one half-chunk (16 k-steps) ahead; every B fragment (32 pixels
+//               x 16 k of h1) read from LDS feeds one 32-cycle MFMA, so the LDS array runs at half its rate
+//               instead of saturated (16x16x32 tiles, generation 1)                         -> h2 chunk in LDS
+//   5. conv3    3x3 512->Cout: each h2 chunk is consumed at once as a K-slice (9 taps = shifted LDS rows); wave w
+//               takes the w-th 32 channels of the chunk for all 9 taps; reduced across waves through LDS at the end
+//   6. tail     bias, exp(3 logs), sigmoid(.+2), (z2+shift)*scale, per-tile partial sum of log-scales
+//   h1 / h2 never travel through HBM between the convolutions; when a backward will follow they are copied out
+//   once, from LDS, in whole 16-byte pieces of contiguous rows.
+// No integer division on the device: W, H and the tile sizes are powers of two (shifts); divisions by C and its
+// relatives use a multiply-high with a reciprocal computed once per kernel.
+#include "nfk_internal.h"
+
+namespace nfk {
+
+typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
+
+struct F2Args {
+  FusedCall c;
+  int R, TS, halo;       // rows per tile, samples per tile, 1 if the tile needs halo rows
+  int lw, lrw, lhw;      // log2(W), log2(R*W), log2(RH*W) (the last only meaningful when TS > 1)
+};
+
+struct F2Geom {
+  int RH, RZ, P_h, MT32, K1, K1M, K1p, X1S, NT3;
+  size_t oZm, oWf, oPar, oX1, oH1, oH2c, oZero, total;
+};
+
+__host__ __device__ static inline F2Geom f2_geom(const nfk_step2d& s, int R, int TS, int halo) {
+  F2Geom g;
+  const int W = s.W, C = s.C, Ch = C / 2;
+  g.RH = R + 2 * halo;
+  g.RZ = R + 4 * halo;
+  g.P_h = TS * g.RH * W;
+  g.MT32 = (g.P_h + 31) / 32;
+  g.K1 = 9 * Ch;
+  g.K1M = g.K1 <= 64 ? 4 : (g.K1 <= 128 ? 8 : 16);   // conv1 k-steps of 16 (zero columns pad the im2col tile)
+  g.K1p = g.K1M * 16;
+  g.X1S = g.K1p * 2 + 16;                            // bytes per im2col row: an odd number of 16-byte slots
+  g.NT3 = (s.Cout + 15) / 16;
+  size_t o = 0;
+  g.oZm = o; o += (size_t)TS * g.RZ * W * C * 4;
+  o = (o + 15) & ~size_t(15);
+  g.oWf = o; o += (size_t)(C * ((C + 3) & ~3) + C) * 4;
+  o = (o + 15) & ~size_t(15);
+  g.oPar = o; o += (size_t)(4 * s.hidden + 2 * ((s.Cout + 3) & ~3)) * 4;
+  g.oX1 = o; o += (size_t)g.MT32 * 32 * g.X1S;
+  o = (o + 15) & ~size_t(15);
+  g.oH1 = o; o += (size_t)g.MT32 * 32 * 1024;
+  g.oH2c = o; o += (size_t)g.MT32 * 32 * 256;
+  g.oZero = o; o += 16;   // sixteen zero bytes: conv3's zero padding reads them instead of masking fragments
+  g.total = o;
+  return g;
+}
+
+__device__ __forceinline__ unsigned f2_pack(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2p __attribute__((ext_vector_type(2)));
+  const f32x2p f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair with ReLU applied on the packed halves (sign bit set <=> negative as int16)
+__device__ __forceinline__ unsigned f2_relu_pack(f32x2 v) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 b = __builtin_convertvector(v, bf16x2);   // one v_cvt_pk_bf16_f32
+  s16x2 h = __builtin_bit_cast(s16x2, b);
+  const s16x2 z = {0, 0};
+  h = __builtin_elementwise_max(h, z);
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f2_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// 16-byte weight fragment: lane-constant voff + scalar soff (+ a compile-time constant folded into the instruction)
+__device__ __forceinline__ bf16x8f f2_ldw(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// h1 image: 1024-byte rows (512 channels); the low 4 bits of the 16-byte slot index are XORed with the pixel index
+__device__ __forceinline__ int f2_h1_off(int px, int slot) {
+  return px * 1024 + ((((slot ^ px) & 15) | (slot & ~15)) << 4);
+}
+// h2 chunk image: 256-byte rows (128 channels = 16 slots), slot ^ (px & 15)
+__device__ __forceinline__ int f2_h2_off(int px, int slot) { return px * 256 + (((slot ^ px) & 15) << 4); }
+
+template <int MT32, int NT3, int K1M>
+__global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
+  constexpr int HID = 512;
+  constexpr int MT_O = 4;   // 64 output pixels = 4 tiles of 16 (conv3 uses 16x16x32)
+  extern __shared__ __attribute__((aligned(16))) char smem_f2[];
+  const nfk_step2d& s = a.c.s;
+  const int W = s.W, H = s.H, C = s.C, Ch = C / 2, C2 = C - Ch, Cout = s.Cout, HW = H * W;
+  const int R = a.R, TS = a.TS, halo = a.halo, lw = a.lw, lrw = a.lrw, lhw = a.lhw;
+  const F2Geom g = f2_geom(s, R, TS, halo);
+  float* Zm = reinterpret_cast<float*>(smem_f2 + g.oZm);
+  float* Wl = reinterpret_cast<float*>(smem_f2 + g.oWf);
+  char* X1 = smem_f2 + g.oX1;
+  char* H1 = smem_f2 + g.oH1;
+  char* H2c = smem_f2 + g.oH2c;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l32 = lane & 31, hi = lane >> 5;      // 32x32x16 operand roles: row / k-half
+  const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 operand roles (conv3)
+
+  const int tps = (TS == 1) ? H / R : 1;
+  const int b0 = (TS == 1) ? blockIdx.x / tps : blockIdx.x * TS;
+  const int tile = (TS == 1) ? blockIdx.x - b0 * tps : 0;
+  const int row0 = tile * R;
+  const int zh = 2 * halo;
+  auto stamp = [&](int i) {
+    if (a.c.stamps && tid == 0) a.c.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
+  };
+  stamp(0);
+
+  // ------------------------------------------------------------------ 0. conv1 weights -> registers (in flight during 1./2.)
+  // Weights come in MFMA-fragment order (nfk_repack_desc.wf): fragment f of an array is the 1 KiB at f*1024, lane l
+  // owns bytes [16 l, 16 l + 16): every wave-load is one contiguous KiB (8 whole cache lines) at a scalar offset.
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+  const int voffL = lane * 16;
+  const int Kp1 = (g.K1 + 63) / 64 * 64;   // padded K of conv1 (== K1M * 16, checked on the host)
+  constexpr int W1R = (K1M >= 16) ? 2 : 4;  // register ring: tiles of 32 output channels held ahead
+  bf16x8f w1[W1R][K1M];
+  const __amdgpu_buffer_rsrc_t r1 = f2_rsrc(s.wf1, (unsigned)HID * Kp1 * 2);
+  auto load_w1 = [&](int j, bf16x8f (&f)[K1M]) {   // row tile (32 channels) swid*4 + j
+    const int soff = (swid * 4 + j) * K1M * 1024;
+#pragma unroll
+    for (int ks = 0; ks < K1M; ++ks) f[ks] = f2_ldw(r1, voffL, soff + ks * 1024);
+  };
+
+  // ------------------------------------------------------------------ 1. mix
+  // Every global load of the prologue is issued before the first wait (x first: it is needed first and the vector
+  // memory returns in order); each of these is an L2 miss, and taken one loop after the other they cost a miss each.
+  const int Cp = (C + 3) & ~3;
+  constexpr int XMAX = 12, WMAX = 9;   // per-thread slots: TS*RZ*W*C <= 3072, C*C <= 2304 (checked on the host)
+  const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;   // idx / C == umulhi(idx, mC) for the small idx used here
+  const int rowlen = W * C, per_s = g.RZ * rowlen, nx = TS * per_s;
+  float* Pb1 = reinterpret_cast<float*>(smem_f2 + g.oPar);
+  float* Pe1 = Pb1 + HID;
+  float* Pb2 = Pe1 + HID;
+  float* Pe2 = Pb2 + HID;
+  float* Pb3 = Pe2 + HID;
+  float* Pe3 = Pb3 + ((Cout + 3) & ~3);
+  float* Xraw = reinterpret_cast<float*>(H1);   // raw x rows of the tile (+halo), staged in the still free h1 region
+  {
+    // the tile's rows (+halo) of all its samples are one run of pixels in x: element e = (pixel, channel)
+    const int lo = (TS == 1) ? max(0, zh - row0) * rowlen : 0;                         // elements inside the image
+    const int hi_e = (TS == 1) ? min(g.RZ, H - row0 + zh) * rowlen : min(s.B - b0, TS) * per_s;   // ... and the batch
+    const float* xb = a.c.x + ((long)b0 * HW + (long)(row0 - zh) * W) * a.c.ldx;
+    float xreg[XMAX], wreg[WMAX], preg[2][4];
+#pragma unroll
+    for (int i = 0; i < XMAX; ++i) {
+      const int e = min(max(tid + 256 * i, lo), hi_e - 1);   // clamped: the load itself is unconditional
+      const int pix = (int)__umulhi((unsigned)e, mC), ch = e - pix * C;
+      xreg[i] = xb[(long)pix * a.c.ldx + ch];
+    }
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) wreg[i] = s.Wf[min(tid + 256 * i, C * C - 1)];
+    const float cfr = s.cf[min(tid, C - 1)];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      preg[i][0] = s.b1[idx]; preg[i][1] = s.es1[idx]; preg[i][2] = s.b2[idx]; preg[i][3] = s.es2[idx];
+    }
+    const float b3r = s.bias3[min(tid, Cout - 1)], e3r = s.es3[min(tid, Cout - 1)];
+#pragma unroll
+    for (int i = 0; i < XMAX; ++i) {
+      const int e = tid + 256 * i;
+      if (e < nx) Xraw[e] = (e >= lo && e < hi_e) ? xreg[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < C * C) {
+        const int o = (int)__umulhi((unsigned)idx, mC), c = idx - o * C;
+        Wl[c * Cp + o] = wreg[i];
+      }
+    }
+    if (tid < C) Wl[C * Cp + tid] = cfr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // (a + b) * e is evaluated as fma(a, e, b*e)
+      const int idx = tid + 256 * i;
+      Pb1[idx] = preg[i][0] * preg[i][1]; Pe1[idx] = preg[i][1];
+      Pb2[idx] = preg[i][2] * preg[i][3]; Pe2[idx] = preg[i][3];
+    }
+    if (tid < Cout) { Pb3[tid] = b3r; Pe3[tid] = e3r; }
+    if (tid < 4) reinterpret_cast<unsigned*>(smem_f2 + g.oZero)[tid] = 0u;
+  }
+  // conv1's weight fragments travel during the mix and the im2col
+#pragma unroll
+  for (int j = 0; j < W1R; ++j) load_w1(j, w1[j]);
+  __syncthreads();
+  {
+    const int G4 = Cp / 4, npz = TS * g.RZ * W;
+    const unsigned mG = 0xFFFFFFFFu / (unsigned)G4 + 1u;
+    const int lzw = lhw;   // TS > 1 implies halo == 0: RZ == RH
+    for (int t = tid; t < npz * G4; t += 256) {
+      const int pz = (int)__umulhi((unsigned)t, mG), o = (t - pz * G4) * 4;
+      const int sm = (TS == 1) ? 0 : (pz >> lzw), rem = (TS == 1) ? pz : (pz & ((1 << lzw) - 1));
+      const int rz = rem >> lw, xx = rem & (W - 1);
+      const int y = row0 + rz - zh, b = b0 + sm;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const bool ok = (unsigned)y < (unsigned)H && b < s.B;
+      if (ok) {
+        const float* xr = Xraw + pz * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < C) acc[r] = Wl[C * Cp + o + r];
+        for (int c = 0; c < C; ++c) {
+          const float xv = xr[c];
+          const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp + o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (o + r < C) Zm[pz * C + o + r] = acc[r];
+      if (ok && a.c.zsave && rz >= zh && rz < zh + R) {
+        float* zp = a.c.zsave + ((long)b * HW + y * W + xx) * C + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < C) zp[r] = acc[r];
+      }
+    }
+  }
+  __syncthreads();
+  stamp(1);
+
+  // ------------------------------------------------------------------ 2. im2col of z1 on the h-region (bf16 pairs)
+  {
+    const int npad = (g.K1p - g.K1) >> 1;   // zero pairs behind the last tap (K1 = 9*Ch is even)
+    for (int t = tid; t < MT32 * 32 * 10; t += 256) {
+      const int ph = (int)__umulhi((unsigned)t, 429496730u), tap = t - ph * 10;
+      char* dst = X1 + ph * g.X1S;
+      if (tap == 9) {
+        unsigned* d = reinterpret_cast<unsigned*>(dst + g.K1 * 2);
+        for (int e = 0; e < npad; ++e) d[e] = 0u;
+        continue;
+      }
+      const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
+      const int rr = rem >> lw, xx = rem & (W - 1);
+      const int t3 = (tap * 11) >> 5;               // tap / 3 for tap < 9
+      const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+      const int rz = rr + halo + dy, xn = xx + dx;  // Zm has `zh` halo rows, the h-region `halo`
+      const bool ok = ph < g.P_h && (unsigned)rz < (unsigned)g.RZ && (unsigned)xn < (unsigned)W;
+      const float* src = Zm + ((sm * g.RZ + rz) * W + xn) * C;
+      unsigned* d = reinterpret_cast<unsigned*>(dst + tap * Ch * 2);
+      for (int ci = 0; ci < Ch; ci += 2) d[ci >> 1] = ok ? f2_pack(src[ci], src[ci + 1]) : 0u;
+    }
+  }
+  __syncthreads();
+  stamp(2);
+
+  // this lane's h-region pixel in each 32-pixel tile: inside the image?  (conv3's zero padding is applied to h2)
+  unsigned hmask[MT32];
+#pragma unroll
+  for (int mt = 0; mt < MT32; ++mt) {
+    const int ph = mt * 32 + l32;
+    const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
+    const int rr = rem >> lw;
+    const int y = row0 + rr - halo, b = b0 + sm;
+    hmask[mt] = (ph < g.P_h && (unsigned)y < (unsigned)H && b < s.B) ? 0xFFFFFFFFu : 0u;
+  }
+  // coalesced copy of the 64 output pixels' rows of an LDS image to a global [M][512] bf16 array (16-byte pieces)
+  auto save_rows = [&](__bf16* dstg, int col0, const char* img, int slots_log2, bool is_h1) {
+    const int spr = 1 << slots_log2;                 // 16-byte slots per row
+    const int slot = tid & (spr - 1);
+    for (int po = tid >> slots_log2; po < 64; po += (256 >> slots_log2)) {
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+      const int b = b0 + sm;
+      if (b >= s.B) continue;
+      const int ph = sm * g.RH * W + (rr + halo) * W + xx;
+      const long m = (long)b * HW + (row0 + rr) * W + xx;
+      const u32x4f v = *reinterpret_cast<const u32x4f*>(img + (is_h1 ? f2_h1_off(ph, slot) : f2_h2_off(ph, slot)));
+      *reinterpret_cast<u32x4f*>(dstg + m * HID + col0 + slot * 8) = v;
+    }
+  };
+
+  // ------------------------------------------------------------------ 3. conv1 -> H1
+  constexpr int Kp2 = HID, Kp3 = 9 * HID;    // both multiples of 64: no row padding
+  bf16x8f w2a[16], w2b[16];
+  const __amdgpu_buffer_rsrc_t r2 = f2_rsrc(s.wf2, (unsigned)HID * Kp2 * 2);
+  const __amdgpu_buffer_rsrc_t r3 = f2_rsrc(s.wf3, (unsigned)NT3 * 16 * Kp3 * 2);
+  auto load_w2 = [&](int nc, int half, bf16x8f (&f)[16]) {   // row tile nc*4 + swid, k-steps half*16 ..
+    const int soff = ((nc * 4 + swid) * (Kp2 / 16) + half * 16) * 1024;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) f[u] = f2_ldw(r2, voffL, soff + u * 1024);
+  };
+  // the first chunk's W2 rows travel while conv1 computes
+  load_w2(0, 0, w2a);
+  load_w2(0, 1, w2b);
+  {
+    const char* x1_lane = X1 + l32 * g.X1S + hi * 16;
+    char* h1w[MT32];
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt) h1w[mt] = H1 + (mt * 32 + l32) * 1024 + 8 * hi;
+    // the im2col fragments are the same for all four channel tiles: where they fit they are read from LDS once
+    constexpr bool XB_REG = (K1M * MT32 <= 16);
+    constexpr int XBN = XB_REG ? K1M : 2;
+    bf16x8f xb[XBN][MT32];
+    auto rd1 = [&](int ks, bf16x8f (&f)[MT32]) {
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+        f[mt] = *reinterpret_cast<const bf16x8f*>(x1_lane + mt * 32 * g.X1S + ks * 32);
+    };
+    if (XB_REG) {
+#pragma unroll
+      for (int ks = 0; ks < K1M; ++ks) rd1(ks, xb[ks]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x16 acc[MT32];
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      if (!XB_REG) rd1(0, xb[0]);
+#pragma unroll
+      for (int ks = 0; ks < K1M; ++ks) {
+        if (!XB_REG) {
+          if (ks + 1 < K1M) rd1(ks + 1, xb[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[j % W1R][ks], xb[XB_REG ? ks : (ks & 1)][mt], acc[mt],
+                                                            0, 0, 0);
+        if (!XB_REG) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (j + W1R < 4) load_w1(j + W1R, w1[j % W1R]);
+      const int n0 = (wid * 4 + j) * 32 + 4 * hi;
+      // h1 write address: px*1024 + (((slot ^ px) & 15) | (slot & 48)) * 16 + 8*hi with slot = wid*16 + j*4 + gi:
+      // the low 2 slot bits are gi, so (slot ^ px) & 15 = ((j*4 + gi) ^ (px & 15)); px & 15 = l32 & 15 in every tile
+      int h1ws[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) h1ws[gi] = ((((j * 4 + gi) ^ l32) & 15) << 4) + wid * 256;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int n = n0 + 8 * gi;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(Pb1 + n), es = *reinterpret_cast<const f32x4*>(Pe1 + n);
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt) {
+          const f32x2 v0 = f32x2{acc[mt][4 * gi], acc[mt][4 * gi + 1]} * f32x2{es[0], es[1]} + f32x2{bb[0], bb[1]};
+          const f32x2 v1 = f32x2{acc[mt][4 * gi + 2], acc[mt][4 * gi + 3]} * f32x2{es[2], es[3]} + f32x2{bb[2], bb[3]};
+          const u32x2f pk = {f2_relu_pack(v0), f2_relu_pack(v1)};
+          *reinterpret_cast<u32x2f*>(h1w[mt] + h1ws[gi]) = pk;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.c.h1save) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, true);
+  stamp(3);
+
+  // ------------------------------------------------------------------ 4./5. conv2 chunks feeding conv3
+  f32x4 acc3[NT3][MT_O];
+#pragma unroll
+  for (int i = 0; i < NT3; ++i)
+#pragma unroll
+    for (int j = 0; j < MT_O; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // conv3 B operand: byte offset into the h2 chunk image per (tap, output m-tile); lane constants
+  int c3_off[9][MT_O];
+#pragma unroll
+  for (int mo = 0; mo < MT_O; ++mo) {
+    const int po = mo * 16 + r16;
+    const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = (rem >> lw) + halo, xx = rem & (W - 1);
+    const int base = sm * g.RH * W;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int rn = rr + dy, xn = xx + dx;
+      const bool ok = (unsigned)rn < (unsigned)g.RH && (unsigned)xn < (unsigned)W;
+      const int rc = min(max(rn, 0), g.RH - 1), xc = min(max(xn, 0), W - 1);
+      c3_off[tap][mo] = ok ? (int)g.oH2c + f2_h2_off(base + rc * W + xc, wid * 4 + q4) : (int)g.oZero;
+    }
+  }
+  bf16x8f w3[9][NT3];
+  auto load_w3 = [&](int nc, int tap) {   // k-step (of 32) tap*16 + nc*4 + swid of every row tile; rows behind Cout are zero
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt)
+      w3[tap][nt] = f2_ldw(r3, voffL, (nt * (Kp3 / 32) + tap * 16 + nc * 4 + swid) * 1024);
+  };
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) load_w3(0, tap);   // chunk 0; later chunks are reloaded in place by conv3
+  // h1 B-fragment address: px = mt*32 + l32 (px & 15 == l32 & 15), slot = 2*ks + hi:
+  //   px*1024 + ((((2ks) & 15) ^ pc) | ((2ks) & 48)) * 16   with the lane constant pc = (l32 & 15) ^ hi
+  // the XOR term takes 8 values per lane (k-step mod 8): 8 lane-constant addresses; m-tile and k-step/8 are immediates
+  const int pc = (l32 & 15) ^ hi;
+  const char* h1r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h1r[e] = H1 + l32 * 1024 + (((2 * e) ^ pc) << 4);
+  f32x16 acc2[MT32];
+  // h2 chunk write address: px*256 + (((wid*4 + gi) ^ px) & 15) * 16 + 8*hi
+  char* h2w[MT32];
+  int h2ws[4];
+#pragma unroll
+  for (int mt = 0; mt < MT32; ++mt) h2w[mt] = H2c + (mt * 32 + l32) * 256 + 8 * hi;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) h2ws[gi] = (((wid * 4 + gi) ^ l32) & 15) << 4;
+  // The weight streams are reloaded IN PLACE between the MFMAs: right after its last use a W2 fragment register
+  // receives the same fragment of the next chunk, and conv3 does the same with its W3 fragments: every weight byte is
+  // requested a whole chunk (thousands of cycles: an L2 miss to the Infinity Cache / HBM is covered) before its use, and
+  // one load per k-step keeps the vector-memory issue (16 cycles per KiB and CU) under the MFMAs instead of stalling
+  // all four waves in a burst.
+  auto conv2_half = [&](int half, bf16x8f (&fa)[16], int nc, int nn) {
+    const int soff_next = ((nn * 4 + swid) * (Kp2 / 16) + half * 16) * 1024;
+    bf16x8f fb[2][MT32];
+    auto rd2 = [&](int u, bf16x8f (&f)[MT32]) {
+      const int ks = half * 16 + u;
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+        f[mt] = *reinterpret_cast<const bf16x8f*>(h1r[ks & 7] + mt * 32768 + (ks >> 3) * 256);
+    };
+    rd2(0, fb[0]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u + 1 < 16) rd2(u + 1, fb[(u + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], fb[u & 1][mt], acc2[mt], 0, 0, 0);
+      fa[u] = f2_ldw(r2, voffL, soff_next + u * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto conv3_chunk = [&](int nn) {
+    // a tap is only 4*NT3 short MFMAs: the LDS reads run three taps ahead
+    bf16x8f fb[4][MT_O];
+    auto rd3 = [&](int tap, bf16x8f (&f)[MT_O]) {
+#pragma unroll
+      for (int mo = 0; mo < MT_O; ++mo) f[mo] = *reinterpret_cast<const bf16x8f*>(smem_f2 + c3_off[tap][mo]);
+    };
+    rd3(0, fb[0]);
+    rd3(1, fb[1]);
+    rd3(2, fb[2]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 3 < 9) rd3(tap + 3, fb[(tap + 3) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mo = 0; mo < MT_O; ++mo)
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt)
+          acc3[nt][mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[tap][nt], fb[tap & 3][mo], acc3[nt][mo], 0, 0, 0);
+      load_w3(nn, tap);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int nc = 0; nc < 4; ++nc) {
+    const int nn = min(nc + 1, 3);   // prefetches are unconditional (clamped): loads under a branch defeat vmcnt counting
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+    conv2_half(0, w2a, nc, nn);
+    conv2_half(1, w2b, nc, nn);
+    if (nc > 0) __syncthreads();
+    // every wave is done with the previous chunk image (conv3 and the h2 copy-out)
+    const int nl = wid * 32 + 4 * hi;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int n = nc * 128 + nl + 8 * gi;
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(Pb2 + n), es = *reinterpret_cast<const f32x4*>(Pe2 + n);
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt) {
+        const f32x2 v0 = f32x2{acc2[mt][4 * gi], acc2[mt][4 * gi + 1]} * f32x2{es[0], es[1]} + f32x2{bb[0], bb[1]};
+        const f32x2 v1 = f32x2{acc2[mt][4 * gi + 2], acc2[mt][4 * gi + 3]} * f32x2{es[2], es[3]} + f32x2{bb[2], bb[3]};
+        const u32x2f pk = {f2_relu_pack(v0) & hmask[mt], f2_relu_pack(v1) & hmask[mt]};   // zero padding of conv3
+        *reinterpret_cast<u32x2f*>(h2w[mt] + h2ws[gi]) = pk;
+      }
+    }
+    __syncthreads();
+    if (a.c.h2save) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), nc * 128, H2c, 4, false);
+    conv3_chunk(nn);
+  }
+  __syncthreads();
+  stamp(4);
+
+  // ------------------------------------------------------------------ 6. cross-wave reduction of conv3, coupling tail
+  float* R3 = reinterpret_cast<float*>(H1);     // [4 waves][64 px][NT3*16]   (h1 is dead now)
+  constexpr int NP = NT3 * 16;
+#pragma unroll
+  for (int nt = 0; nt < NT3; ++nt)
+#pragma unroll
+    for (int mo = 0; mo < MT_O; ++mo)
+      *reinterpret_cast<f32x4*>(R3 + ((wid * 64 + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc3[nt][mo];
+  __syncthreads();
+  __shared__ float sh2[32];
+  const int per_px = R * W;
+  const unsigned mC2 = 0xFFFFFFFFu / (unsigned)C2 + 1u, mCh = 0xFFFFFFFFu / (unsigned)Ch + 1u;
+  for (int sm = 0; sm < TS; ++sm) {
+    const int b = b0 + sm;
+    float ls = 0.f;
+    if (b < s.B) {
+      for (int idx = tid; idx < per_px * C2; idx += 256) {
+        const int pl = (int)__umulhi((unsigned)idx, mC2), j = idx - pl * C2, rr = pl >> lw, xx = pl & (W - 1);
+        const int po = sm * per_px + pl;
+        const long m = (long)b * HW + (row0 + rr) * W + xx;
+        const float z2 = Zm[((sm * g.RZ + rr + zh) * W + xx) * C + Ch + j];
+        auto a3 = [&](int n) {
+          const float* p = R3 + po * NP + n;
+          return ((p[0] + p[64 * NP]) + (p[2 * 64 * NP] + p[3 * 64 * NP]) + Pb3[n]) * Pe3[n];
+        };
+        float out;
+        if (s.additive) {
+          const float h = a3(j);
+          if (a.c.hsave) a.c.hsave[m * Cout + j] = h;
+          out = z2 + h;
+        } else {
+          const float sh = a3(2 * j), sr = a3(2 * j + 1);
+          if (a.c.hsave) { a.c.hsave[m * Cout + 2 * j] = sh; a.c.hsave[m * Cout + 2 * j + 1] = sr; }
+          const float t = sr + 2.f;
+          out = (z2 + sh) * sigmoidf(t);
+          ls += log_sigmoidf(t);
+        }
+        a.c.zout[m * C + Ch + j] = out;
+      }
+      for (int idx = tid; idx < per_px * Ch; idx += 256) {
+        const int pl = (int)__umulhi((unsigned)idx, mCh), j = idx - pl * Ch, rr = pl >> lw, xx = pl & (W - 1);
+        a.c.zout[((long)b * HW + (row0 + rr) * W + xx) * C + j] = Zm[((sm * g.RZ + rr + zh) * W + xx) * C + j];
+      }
+    }
+    ls = block_sum(ls, sh2);
+    if (tid == 0 && b < s.B) a.c.ldpart[(long)b * tps + tile] = ls + (tile == 0 ? s.dld[0] : 0.f);
+  }
+  stamp(5);
+}
+
+static int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+static bool f2_pick(const nfk_step2d& s, F2Args* a) {
+  if (!s.bf16 || s.hidden != 512 || s.Cout > 48 || s.Cout < 1 || (s.C & 3) != 0 || s.C < 4) return false;
+  if (!s.wf1 || !s.wf2 || !s.wf3) return false;   // needs the fragment-ordered weight copies
+  const int lw = ilog2_exact(s.W), lh = ilog2_exact(s.H);
+  if (lw < 0 || lh < 0) return false;
+  const int HW = s.H * s.W;
+  if (HW <= 64) { a->R = s.H; a->TS = 64 / HW; a->halo = 0; }
+  else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) { a->R = 64 / s.W; a->TS = 1; a->halo = 1; }
+  else return false;
+  const F2Geom g = f2_geom(s, a->R, a->TS, a->halo);
+  if (g.MT32 != 2 && g.MT32 != 3) return false;
+  if (g.K1 > 256 || g.K1M * 16 != (g.K1 + 63) / 64 * 64) return false;   // wf1's k extent must be K1M k-steps
+  if (g.total > 160 * 1024 - 512) return false;
+  if ((size_t)4 * 64 * g.NT3 * 16 * 4 > (size_t)g.MT32 * 32 * 1024) return false;   // R3 lives in the h1 region
+  if ((size_t)a->TS * g.RZ * s.W * s.C * 4 > (size_t)g.MT32 * 32 * 1024) return false;  // so does the raw x staging
+  if (a->TS * g.RZ * s.W * s.C > 12 * 256 || s.C * s.C > 9 * 256 || s.Cout > 256) return false;  // prologue register slots
+  a->lw = lw;
+  a->lrw = ilog2_exact(a->R * s.W);
+  a->lhw = ilog2_exact(g.RH * s.W);   // -1 when TS == 1 with halo rows: unused there
+  if (a->lrw < 0 || (a->TS > 1 && a->lhw < 0)) return false;
+  if (a->lhw < 0) a->lhw = 0;
+  return true;
+}
+
+template <int MT32, int NT3, int K1M>
+static int f2_launch_t(const F2Args& a, const F2Geom& g, int grid, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_step_fwd_kernel<MT32, NT3, K1M>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+      return NFK_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((fused2_step_fwd_kernel<MT32, NT3, K1M>), dim3(grid), dim3(256), g.total, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+template <int MT32>
+static int f2_dispatch(const F2Args& a, const F2Geom& g, int grid, hipStream_t st) {
+  // instantiated for the shapes Glow produces: conv3 width grows with conv1's K (both follow C)
+  if (g.NT3 == 1 && g.K1M == 4) return f2_launch_t<MT32, 1, 4>(a, g, grid, st);
+  if (g.NT3 == 2 && g.K1M == 8) return f2_launch_t<MT32, 2, 8>(a, g, grid, st);
+  if (g.NT3 == 3 && g.K1M == 16) return f2_launch_t<MT32, 3, 16>(a, g, grid, st);
+  return NFK_ERR_ARG;
+}
+
+int fused2_tiles(const nfk_step2d& s) {
+  F2Args a{};
+  if (!f2_pick(s, &a)) return 0;
+  const F2Geom g = f2_geom(s, a.R, a.TS, a.halo);
+  const bool inst = (g.NT3 == 1 && g.K1M == 4) || (g.NT3 == 2 && g.K1M == 8) || (g.NT3 == 3 && g.K1M == 16);
+  if (!inst) return 0;
+  return a.TS == 1 ? s.H / a.R : 1;
+}
+
+int fused2_launch(const FusedCall& c, hipStream_t st) {
+  F2Args a{};
+  if (!f2_pick(c.s, &a)) return NFK_ERR_ARG;
+  a.c = c;
+  const F2Geom g = f2_geom(c.s, a.R, a.TS, a.halo);
+  const int grid = a.TS == 1 ? c.s.B * (c.s.H / a.R) : (c.s.B + a.TS - 1) / a.TS;
+  return g.MT32 == 2 ? f2_dispatch<2>(a, g, grid, st) : f2_dispatch<3>(a, g, grid, st);
+}
+
+}  // namespace nfk

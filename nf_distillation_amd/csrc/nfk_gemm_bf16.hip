@@ -296,11 +296,30 @@ __global__ void repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ des
   const nfk_repack_desc d = descs[blockIdx.y];
   const int Kp = (d.taps * d.Cin + BKH - 1) / BKH * BKH, Kpd = (d.taps * d.Cout + BKH - 1) / BKH * BKH;
   const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
+  const int rows_g = (d.frag == 1) ? d.Cout : (d.Cout + 15) / 16 * 16;
+  const long total_g = (d.wf && d.frag) ? (long)rows_g * Kp : 0;
   __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
-  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d;
+  __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d + total_g;
        t += (long)gridDim.x * blockDim.x) {
-    if (t < total_f) {
+    if (t >= total_f + total_d) {
+      // fragment order: element e of lane `lane` of the A operand of k-step ks of row tile nt
+      const long u = t - total_f - total_d;
+      const int e = u & 7, lane = (u >> 3) & 63;
+      const long fr = u >> 9;
+      int co, k;
+      if (d.frag == 1) {   // 32x32x16: 32 rows x 16 k per fragment
+        const int KS = Kp / 16, nt = fr / KS, ks = fr - (long)nt * KS;
+        co = nt * 32 + (lane & 31); k = ks * 16 + (lane >> 5) * 8 + e;
+      } else {             // 16x16x32: 16 rows x 32 k per fragment
+        const int KS = Kp / 32, nt = fr / KS, ks = fr - (long)nt * KS;
+        co = nt * 16 + (lane & 15); k = ks * 32 + (lane >> 4) * 8 + e;
+      }
+      float v = 0.f;
+      if (co < d.Cout && k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];
+      wf[u] = (__bf16)v;
+    } else if (t < total_f) {
       const int co = t / Kp, k = t % Kp;
       float v = 0.f;
       if (k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];

@@ -107,6 +107,22 @@ struct PriorBwdArgs {
   int HW, C; float bpd_scale;
 };
 
+// one fused FlowStep forward call (nfk_fused.hip / nfk_fused2.hip)
+struct FusedCall {
+  nfk_step2d s;
+  const float* x; int ldx;
+  float* zsave;          // [M][C]   mixed z (training) or null
+  void* h1save;          // [M][hid] bf16 or null
+  void* h2save;          // [M][hid] bf16 or null
+  float* hsave;          // [M][Cout] or null
+  float* zout;           // [M][C]
+  float* ldpart;         // [B][tiles per sample] partial log-det of this step
+  unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
+  int dbg;                     // diagnostic bisect bits (0 in production)
+};
+int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
+int fused2_launch(const FusedCall& c, hipStream_t st);
+
 void set_tuning(int v);
 void prof_begin();
 void prof_end(double* ms, long long* launches, double* flops, double* bytes);

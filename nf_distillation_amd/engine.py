@@ -138,6 +138,12 @@ class FlowEngine:
                                     ("wt3", r.Cout * pk(9 * hid)), ("wd3", hid * pk(9 * r.Cout))):
                         off[name] = o
                         o += (n + 7) & ~7
+                    if self.bf16 and hid % 32 == 0:
+                        # fragment-ordered copies of the forward weights for the fused step kernel (nfk_fused2.hip)
+                        for name, n in (("wf1", hid * pk(9 * Ch)), ("wf2", hid * pk(hid)),
+                                        ("wf3", (r.Cout + 15) // 16 * 16 * pk(9 * hid))):
+                            off[name] = o
+                            o += (n + 7) & ~7
                     step_pack = o
                 plan.append((r, off))
             elif isinstance(layer, M.Split2d):
@@ -208,17 +214,21 @@ class FlowEngine:
                         setattr(cs, nm, pb + 4 * off[nm])
                     for nm in ("wt1", "wt2", "wt3", "wd1", "wd2", "wd3"):
                         setattr(cs, nm, sb + esz * off[nm])
+                    for nm in ("wf1", "wf2", "wf3"):
+                        setattr(cs, nm, sb + esz * off[nm] if nm in off else None)
                     r.cs = cs
                     Ch = r.C // 2
-                    for w, co, ci, taps, a, b in ((blk[0].conv.weight, r.hid, Ch, 9, "wt1", "wd1"),
-                                                  (blk[2].conv.weight, r.hid, r.hid, 1, "wt2", "wd2"),
-                                                  (blk[4].conv.weight, r.Cout, r.hid, 9, "wt3", "wd3")):
+                    for w, co, ci, taps, a, b, f, fk in ((blk[0].conv.weight, r.hid, Ch, 9, "wt1", "wd1", "wf1", 1),
+                                                         (blk[2].conv.weight, r.hid, r.hid, 1, "wt2", "wd2", "wf2", 1),
+                                                         (blk[4].conv.weight, r.Cout, r.hid, 9, "wt3", "wd3", "wf3", 2)):
                         _check_param(w, "conv.weight")
                         if tuple(w.shape) != (co, ci, 3 if taps == 9 else 1, 3 if taps == 9 else 1):
                             raise ValueError(f"layer {r.idx}: unexpected conv weight shape {tuple(w.shape)}")
                         rd = RepackDesc()
                         rd.w, rd.wt, rd.wd = ptr(w), sb + esz * off[a], sb + esz * off[b]
                         rd.Cout, rd.Cin, rd.taps = co, ci, taps
+                        if f in off:
+                            rd.wf, rd.frag = sb + esz * off[f], fk
                         step_repack.append(rd)
                 else:
                     from .tabular import TabStep

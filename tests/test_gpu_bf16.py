@@ -81,10 +81,22 @@ def test_distillation_step_trains():
     assert float(out["result_loss"]) < first
 
 
+@pytest.mark.parametrize("dbg", [0, 0x100, 0x300], ids=["policy", "forced_every_level", "gen1_forced"])
 @pytest.mark.parametrize("name", ["cifar_k8_full", "glow32"])
-def test_fused_step_equals_unfused(name):
-    """The one-launch FlowStep forward (csrc/nfk_fused.hip) against the five-kernel bf16 path: same bf16 roundings
-    of h1/h2/weights, so outputs agree to fp32 summation-order noise; gradients (same backward) likewise."""
+def test_fused_step_equals_unfused(name, dbg):
+    """The one-launch FlowStep forward (csrc/nfk_fused2.hip; generation 1 in nfk_fused.hip) against the five-kernel
+    bf16 path: same bf16 roundings of h1/h2/weights, so outputs agree to fp32 summation-order noise; gradients (same
+    backward) likewise.  `dbg` bit 8 forces the fused step where the policy would not pick it (levels 2 and 3), bit 9
+    selects generation 1."""
+    from nf_distillation_amd import capi
+    capi.lib().nfk_fused_set_debug(dbg)
+    try:
+        _fused_vs_unfused(name)
+    finally:
+        capi.lib().nfk_fused_set_debug(0)
+
+
+def _fused_vs_unfused(name):
     g = Golden(name)
     cfg = g.cfg
     if name.endswith("_full"):

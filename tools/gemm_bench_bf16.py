@@ -22,8 +22,8 @@ layers = list(teacher.flow.layers)
 # teacher: [squeeze, 32 steps, split, squeeze, 32 steps, split, squeeze, 32 steps]
 spans = {"level 1": (0, 33), "level 2": (0, 67), "level 3": (0, 101)}
 prev = 0.0
-for fused in (False, True):
-    lib.nfk_fused_set_debug(0x100 if fused else 0)   # bit 8: force the fused step also for small grids
+for label, fused, dbg in (("5-kernel", False, 0), ("fused gen1", True, 0x300), ("fused gen2", True, 0x100)):
+    lib.nfk_fused_set_debug(dbg)   # bit 8: force the fused step also for small grids, bit 9: generation 1
     prev_t = 0.0
     for name, (a, b) in spans.items():
         e = FlowEngine(layers[a:b])
@@ -41,7 +41,7 @@ for fused in (False, True):
             t1.record()
             torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / 10
-        print(f"{'fused' if fused else '5-kernel'} {name}: cumulative {ms:.3f} ms, this level {ms - prev_t:.3f} ms "
+        print(f"{label} {name}: cumulative {ms:.3f} ms, this level {ms - prev_t:.3f} ms "
               f"= {(ms - prev_t) / 32 * 1e3:.1f} us/step", flush=True)
         prev_t = ms
 lib.nfk_fused_set_debug(0)
