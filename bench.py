@@ -5,13 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Default: bf16 operands / fp32 accumulate (BASELINE.json config 2), the whole step replayed from one hipGraph.
 A "step" = teacher forward (no grad) + student forward/backward + MSE hints on layer pairs
 [0,10,20,28]/[0,34,68,100] + global-norm clip 30 + Adam, on a synthetic
 CIFAR-shaped batch of 64 images per GPU already resident in HBM.  Rank 0 prints ONE JSON line.
 
 Extra legs (rank 0, N=1 only):
-  roofline     : K more steps with the GEMM launchers bracketed by HIP events (nfk_profile_*),
-                 dominant kernel's algorithmic FLOP/s against the f32 MFMA peak (157.3 TFLOP/s).
+  roofline     : K more (eager) steps with every GEMM-engine / fused-step launch bracketed by HIP events on
+                 its own stream (nfk_profile_*); for the kernel class with the largest total time: algorithmic
+                 FLOP/s against the dense MFMA peak of the compute dtype (157.3 TFLOP/s f32, 2.5 PFLOP/s bf16)
+                 or algorithmic bytes/s against HBM (8 TB/s), whichever bound gives the larger minimum time.
   cpu_baseline : the CPU oracle (oracle/glow_oracle.py, a checked restatement of the reference)
                  running the same step on the host cores for a bounded number of steps.
 """
