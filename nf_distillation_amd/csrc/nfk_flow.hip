@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __rest
   part[e] = slab_sum(part, g.nparts, E, e);
 }
 
+constexpr size_t PREP_BWD_LDS = 60 * 1024;
 // Backward of prep: chain (gWf, gcf, G = sum_b g_logdet[b]) to the raw parameters; accumulates.
 //   part: [nparts][C*C + C] partial sums of  gWf[o][c] = sum_m gz[m][o] x[m][c],  gcf[o] = sum_m gz[m][o]
 __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
@@ -184,12 +185,22 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
   const PrepGrad g = grads[blockIdx.x];
   const int C = d.C, CC = C * C;
   if (C == 0) return;
-  float* W = d.scratch;
+  // the C x C work matrices (and P) live in LDS when six of them fit the 60 KiB the launch provides (C <= 50);
+  // wider steps fall back to the step's global scratch
+  extern __shared__ __attribute__((aligned(16))) float pb_lds[];
+  const bool in_lds = (size_t)6 * CC * sizeof(float) <= PREP_BWD_LDS;
+  float* W = in_lds ? pb_lds : d.scratch;
   float* T0 = W + CC;
   float* T1 = T0 + CC;
   float* AUG = T1 + CC;   // 2*CC floats: use as two more matrices
   float* GW = AUG;
   float* T2 = AUG + CC;
+  const float* P = d.p;
+  if (in_lds && d.perm_kind == PERM_LU) {
+    float* Pl = W + 5 * CC;
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];
+    P = Pl;   // visible after the first barrier below
+  }
 
   float G = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) G += gld[b];
@@ -229,7 +240,7 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
       T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
     }
     __syncthreads();
-    blk_matmul(d.p, 1, GW, 0, T2, C);   // T2 = P^T gW
+    blk_matmul(P, 1, GW, 0, T2, C);     // T2 = P^T gW
     blk_matmul(T2, 0, T1, 1, W, C);     // W  = P^T gW U^T   -> g_L
     for (int idx = threadIdx.x; idx < CC; idx += blockDim.x)
       if (idx / C > idx % C) g.g_lower[idx] += W[idx];
@@ -732,7 +743,7 @@ int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int ns
   // C <= 192 covers every supported width: (192*192 + 192) / 256 = 145 chunks
   hipLaunchKernelGGL(part_reduce_kernel, dim3(145, nsteps), dim3(256), 0, st, descs_dev, grads_dev);
   NFK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(prep_bwd_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, grads_dev, gld, B);
+  hipLaunchKernelGGL(prep_bwd_kernel, dim3(nsteps), dim3(256), PREP_BWD_LDS, st, descs_dev, grads_dev, gld, B);
   NFK_LAUNCH_CHECK();
   if (any_dense) {
     hipLaunchKernelGGL(prep_bwd_dense_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, grads_dev, gld, B);
