@@ -177,6 +177,25 @@ int nfk_step2d_inv(const nfk_step2d *s, const float *y, int ldy, const float *ld
 int nfk_step2d_bwd(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
                    const float *h1, const float *h2, const float *hsave, const float *g_out,
                    const float *g_ext, const float *g_ld, float *g_x, float *ws, void *stream);
+/* Same, for a caller that runs many steps back to back with an auxiliary stream set (nfk_set_aux_stream): the three
+ * gradient tensors the weight-gradient GEMMs read are placed in `ga` (nfk_step2d_bwd_ga_floats floats, a buffer of its
+ * own for every step until nfk_aux_join) and their split slabs in `wslab` (nfk_step2d_bwd_wslab_floats floats, may be
+ * shared by all steps: only the auxiliary stream touches it), so that the auxiliary stream is NOT joined inside the
+ * call and the dgrad chain of the next step starts at once.  nfk_aux_join makes `stream` wait for everything queued on
+ * the auxiliary stream; the weight gradients are complete only after it.  Without an auxiliary stream (or with NULL
+ * ga / wslab) this is nfk_step2d_bwd. */
+int nfk_step2d_bwd_deferred(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
+                            const float *h1, const float *h2, const float *hsave, const float *g_out,
+                            const float *g_ext, const float *g_ld, float *g_x, float *ws, float *ga, float *wslab,
+                            void *stream);
+size_t nfk_step2d_bwd_ga_floats(const nfk_step2d *s);
+size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d *s);
+int nfk_aux_join(void *stream);
+/* bf16 backward: run a conv's dgrad GEMM and its weight-gradient GEMM as ONE launch (no second stream, no fork/join
+ * edges in a captured graph).  0 = never, 1 = for steps of at most 4096 pixels (the small launches of the deep levels),
+ * 2 = always (default).  Steps that use it ignore the auxiliary stream. */
+void nfk_set_bwd_mode(int mode);
+void *nfk_get_aux_stream(void);
 /* Fused forward of one FlowStep in ONE launch (bf16 mode, 64-pixel row tiles; see csrc/nfk_fused.hip).
  * nfk_step2d_fused_tiles: 0 if this step's geometry is not supported (use nfk_step2d_fwd), else the number of
  * log-det partial slots per sample.  zsave/h1save/h2save/hsave as in nfk_step2d_fwd (NULL when no backward
@@ -228,7 +247,8 @@ int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const 
 enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW = 2, NFK_PROF_WGRAD_WIDE = 3,
        NFK_PROF_WGRAD_NARROW = 4,
        NFK_PROF_FUSED_STEP = 5, /* nfk_step2d_fwd_fused: flops of the three convs, bytes = x + z + weights (+ saves) */
-       NFK_PROF_CLASSES = 6 };
+       NFK_PROF_DUAL_BWD = 6,   /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode) */
+       NFK_PROF_CLASSES = 7 };
 void nfk_profile_begin(void);
 /* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
  * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */

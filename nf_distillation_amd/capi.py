@@ -110,6 +110,13 @@ _PROTOS = {
     "nfk_step2d_inv": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_step2d_bwd": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp,
                              vp, vp]),
+    "nfk_step2d_bwd_deferred": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp,
+                                      vp, vp, vp, vp, vp]),
+    "nfk_step2d_bwd_ga_floats": (u64, [C.POINTER(Step2d)]),
+    "nfk_step2d_bwd_wslab_floats": (u64, [C.POINTER(Step2d)]),
+    "nfk_aux_join": (i32, [vp]),
+    "nfk_set_bwd_mode": (None, [i32]),
+    "nfk_get_aux_stream": (vp, []),
     "nfk_step2d_fused_tiles": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_set_stamps": (None, [vp]),
     "nfk_fused_set_debug": (None, [i32]),
@@ -149,7 +156,7 @@ def lib():
 
 PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
                 "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>",
-                "fused_step_fwd_kernel (whole FlowStep forward)")
+                "fused_step_fwd_kernel (whole FlowStep forward)", "dual_dgrad_wgrad_bf16_kernel (dgrad + wgrad)")
 
 
 def profile_begin():

@@ -63,6 +63,7 @@ int splitk_of(int bf16, int M, int N, int K) {
 // Optional auxiliary stream: when set, the weight-gradient GEMMs of a step's backward run on it,
 // concurrently with the dgrad chain on the caller's stream (fork/join with events; capturable).
 static hipStream_t g_aux = nullptr;
+static int g_bwd_mode = 2;
 static hipEvent_t g_ev[4];
 static bool g_ev_ready = false;
 static void fork_to_aux(hipStream_t main_st, int i) {
@@ -232,57 +233,75 @@ int nfk_step2d_inv(const nfk_step2d* s, const float* y, int ldy, const float* ld
   return launch_chanmix(m, st);
 }
 
-int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
-                   const float* h1, const float* h2, const float* hsave, const float* g_out, const float* g_ext,
-                   const float* g_ld, float* g_x, float* ws, void* stream) {
+// ga / wslab_ext: see nfk_step2d_bwd_deferred (both NULL = everything inside ws, auxiliary stream joined per call)
+static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
+                           const float* h1, const float* h2, const float* hsave, const float* g_out,
+                           const float* g_ext, const float* g_ld, float* g_x, float* ws, float* ga, float* wslab_ext,
+                           void* stream) {
   hipStream_t st = S_(stream);
   const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, hid = s->hidden, Cout = s->Cout;
   const int M = B * H * W, HW = H * W, bf = s->bf16;
   const StepBwdWs L = step_bwd_layout(s);
   float *ga3 = ws + L.ga3, *gz = ws + L.gz, *ga2 = ws + L.ga2, *ga1 = ws + L.ga1, *d1 = ws + L.d1slab;
   float *col2 = ws + L.col2, *col1 = ws + L.col1, *tail = ws + L.tail, *wslab = ws + L.wslab;
+  const bool deferred = ga != nullptr && wslab_ext != nullptr && g_aux != nullptr && g_aux != st;
+  if (deferred) {   // the three tensors the weight-gradient GEMMs read live in this step's own buffer
+    ga3 = ga;
+    ga2 = ga3 + align4((size_t)M * Cout);
+    ga1 = ga2 + align4((size_t)M * hid);
+    wslab = wslab_ext;
+  }
 
   CouplingBwdArgs cb{};
   cb.gout = g_out; cb.ldg = C; cb.gext = g_ext; cb.ldge = C; cb.gld = g_ld; cb.z = z; cb.ldz = C; cb.h = hsave;
   cb.es3 = s->es3; cb.ga3 = ga3; cb.gz = gz; cb.ldgz = C; cb.part = tail; cb.HW = HW; cb.C = C; cb.Cout = Cout;
   cb.additive = s->additive;
   NFK_TRY(launch_coupling_bwd(cb, B, st));
+  // Each conv's weight gradient (slabs -> finalize) and dgrad read the same output gradient and are independent.
+  // bf16 "dual" mode runs the two GEMMs as ONE launch on the caller's stream; otherwise the weight gradient goes to
+  // the auxiliary stream (if one is set), forked here and joined at the end of the call / by nfk_aux_join.
+  const bool dual = bf && (g_bwd_mode == 2 || (g_bwd_mode == 1 && M <= 4096));
   hipStream_t ws_st = st;  // stream of the wgrad GEMMs
-  if (g_aux && g_aux != st) { ws_st = g_aux; fork_to_aux(st, 0); }
+  const bool use_aux = !dual && g_aux && g_aux != st;
+  if (use_aux) ws_st = g_aux;
+  int fork_i = 0;
+  auto conv_bwd = [&](const ConvGemmArgs& dg, const WgradArgs& wg, int Sw, int Co, int Ci, int taps, float* gw) -> int {
+    if (dual) {
+      const int rc = dual_dgrad_wgrad_bf16(dg, wg, Sw, st);
+      if (rc == NFK_OK) return wgrad_finalize(wslab, Sw, wg.slab_stride, Co, Ci, taps, gw, st);
+      if (rc != NFK_ERR_ARG) return rc;   // NFK_ERR_ARG: this pair of tile shapes is not instantiated
+    }
+    if (use_aux) fork_to_aux(st, fork_i++);
+    NFK_TRY(bf ? wgrad_gemm_bf16(wg, Sw, ws_st) : wgrad_gemm(wg, Sw, ws_st));
+    NFK_TRY(wgrad_finalize(wslab, Sw, wg.slab_stride, Co, Ci, taps, gw, ws_st));
+    return run_conv(bf, dg, st);
+  };
 
-  // conv3 (block.4): wgrad then dgrad
+  // conv3 (block.4)
   WgradArgs w3{};
   w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
   w3.B = B; w3.H = H; w3.W = W; w3.out = wslab; w3.slab_stride = (long)Cout * 9 * hid;
   w3.qbf16 = bf;
-  NFK_TRY(bf ? wgrad_gemm_bf16(w3, L.S3w, ws_st) : wgrad_gemm(w3, L.S3w, ws_st));
-  NFK_TRY(wgrad_finalize(wslab, L.S3w, w3.slab_stride, Cout, hid, 9, g->g_w3, ws_st));
   ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD, bf, 1, bf);
   d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
-  NFK_TRY(run_conv(bf, d3, st));
-  if (ws_st != st) fork_to_aux(st, 1);
+  NFK_TRY(conv_bwd(d3, w3, L.S3w, Cout, hid, 9, g->g_w3));
 
   // conv2 (block.2)
   WgradArgs w2{};
   w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
   w2.B = B; w2.H = H; w2.W = W; w2.out = wslab; w2.slab_stride = (long)hid * hid;
   w2.pbf16 = bf; w2.qbf16 = bf;
-  NFK_TRY(bf ? wgrad_gemm_bf16(w2, L.S2w, ws_st) : wgrad_gemm(w2, L.S2w, ws_st));
-  NFK_TRY(wgrad_finalize(wslab, L.S2w, w2.slab_stride, hid, hid, 1, g->g_w2, ws_st));
   ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
   d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
-  NFK_TRY(run_conv(bf, d2, st));
-  if (ws_st != st) fork_to_aux(st, 2);
+  NFK_TRY(conv_bwd(d2, w2, L.S2w, hid, hid, 1, g->g_w2));
 
   // conv1 (block.0)
   WgradArgs w1{};
   w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = z; w1.ldq = C; w1.Cq = Ch; w1.taps = 9;
   w1.B = B; w1.H = H; w1.W = W; w1.out = wslab; w1.slab_stride = (long)hid * 9 * Ch;
   w1.pbf16 = bf;
-  NFK_TRY(bf ? wgrad_gemm_bf16(w1, L.S1w, ws_st) : wgrad_gemm(w1, L.S1w, ws_st));
-  NFK_TRY(wgrad_finalize(wslab, L.S1w, w1.slab_stride, hid, Ch, 9, g->g_w1, ws_st));
   ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
-  NFK_TRY(run_conv(bf, d1a, st));
+  NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
 
   nfk_small_grad_args sg{};
   sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb; sg.mb2 = L.mb; sg.B = B;
@@ -297,8 +316,38 @@ int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* 
   m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = L.S1; m.slab_stride = (long)M * Ch;
   m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
   NFK_TRY(launch_chanmix(m, st));
-  if (ws_st != st) {  // join: this step's workspace and weight grads are complete when the call's stream moves on
+  if (ws_st != st && !deferred) {  // join: this step's workspace and weight grads are complete when the call's stream moves on
     (void)hipEventRecord(g_ev[3], ws_st);
+    (void)hipStreamWaitEvent(st, g_ev[3], 0);
+  }
+  return NFK_OK;
+}
+
+int nfk_step2d_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
+                   const float* h1, const float* h2, const float* hsave, const float* g_out, const float* g_ext,
+                   const float* g_ld, float* g_x, float* ws, void* stream) {
+  return step2d_bwd_impl(s, g, x, ldx, z, h1, h2, hsave, g_out, g_ext, g_ld, g_x, ws, nullptr, nullptr, stream);
+}
+int nfk_step2d_bwd_deferred(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
+                            const float* h1, const float* h2, const float* hsave, const float* g_out,
+                            const float* g_ext, const float* g_ld, float* g_x, float* ws, float* ga, float* wslab,
+                            void* stream) {
+  return step2d_bwd_impl(s, g, x, ldx, z, h1, h2, hsave, g_out, g_ext, g_ld, g_x, ws, ga, wslab, stream);
+}
+size_t nfk_step2d_bwd_ga_floats(const nfk_step2d* s) {
+  const size_t M = (size_t)s->B * s->H * s->W;
+  return align4(M * s->Cout) + 2 * align4(M * s->hidden);
+}
+size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d* s) {
+  const StepBwdWs L = step_bwd_layout(s);
+  return L.total - L.wslab;
+}
+void* nfk_get_aux_stream(void) { return g_aux; }
+void nfk_set_bwd_mode(int mode) { g_bwd_mode = mode; }
+int nfk_aux_join(void* stream) {
+  hipStream_t st = S_(stream);
+  if (g_aux && g_aux != st) {
+    (void)hipEventRecord(g_ev[3], g_aux);
     (void)hipStreamWaitEvent(st, g_ev[3], 0);
   }
   return NFK_OK;

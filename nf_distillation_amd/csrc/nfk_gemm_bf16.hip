@@ -40,8 +40,10 @@ __device__ __forceinline__ int xcd_remap_b(int id, int n) {
 // byte offset of 16-byte slot `slot` (0..7) of tile row `row` (128-byte rows, XOR swizzle)
 __device__ __forceinline__ int lds_boff(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// The kernel bodies are device functions of (arguments, tile index, split count, split index) so that one launch can
+// run a dgrad GEMM and a wgrad GEMM side by side (dual_dgrad_wgrad_bf16_kernel below).
 template <int TN, int TM, int WN, int WM, bool XF32>
-__global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
+__device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs& a, const int bx, const int S, const int z) {
   static_assert(WN * WM == 4, "256-thread workgroups");
   constexpr int BN = 16 * TN * WN, BM = 16 * TM * WM;
   constexpr int WL = (BN * 8 + 255) / 256, XL = BM / 32;
@@ -50,11 +52,10 @@ __global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid % WN, wm = wid / WN;
   const int nNB = (a.N + BN - 1) / BN, nMB = (a.M + BM - 1) / BM;
-  const int bid = xcd_remap_b(blockIdx.x, nNB * nMB);
+  const int bid = xcd_remap_b(bx, nNB * nMB);
   const int n0 = (bid % nNB) * BN, m0 = (bid / nNB) * BM;
   const int HW = a.H * a.W;
   constexpr int XE = XF32 ? 4 : 2;  // bytes per X element
-  const int S = gridDim.y, z = blockIdx.y;
   const int c_begin = (int)((long)a.nkchunks * z / S), c_end = (int)((long)a.nkchunks * (z + 1) / S);
 
   const __amdgpu_buffer_rsrc_t rX = rsrc_of(a.X, (unsigned)((long)a.M * a.ldx * XE));
@@ -291,6 +292,11 @@ __global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
   }
 }
 
+template <int TN, int TM, int WN, int WM, bool XF32>
+__global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
+  conv_gemm_bf16_body<TN, TM, WN, WM, XF32>(a, blockIdx.x, gridDim.y, blockIdx.y);
+}
+
 // conv.weight [Cout][Cin][taps] (fp32) -> bf16 wt [Cout][Kp64] and wd [Cin][Kp64(taps*Cout)] (flipped taps)
 __global__ void repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ descs) {
   const nfk_repack_desc d = descs[blockIdx.y];
@@ -429,7 +435,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int c0, 
 }
 
 template <int TN, int TM, int WN, int WM>
-__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, const int S, const int z) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
   constexpr int SP = wg_stride(BI), SQ = wg_stride(BJ);
   constexpr int STAGE = WPX * (SP + SQ);
@@ -439,10 +445,9 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid % WN, wm = wid / WN;
   const int nIB = (a.NI + BI - 1) / BI, nJB = (a.J + BJ - 1) / BJ;
-  const int bid = xcd_remap_b(blockIdx.x, nIB * nJB);
+  const int bid = xcd_remap_b(bx, nIB * nJB);
   const int i0 = (bid % nIB) * BI, j0 = (bid / nIB) * BJ;
   const int HW = a.H * a.W;
-  const int S = gridDim.y, z = blockIdx.y;
   const int nchunks = (a.M + WPX - 1) / WPX;
   const int c_begin = (int)((long)nchunks * z / S), c_end = (int)((long)nchunks * (z + 1) / S);
   const unsigned pes = a.pbf16 ? 2u : 4u, qes = a.qbf16 ? 2u : 4u;
@@ -583,6 +588,50 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
 }
 
 template <int TN, int TM, int WN, int WM>
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
+  wgrad_bf16_body<TN, TM, WN, WM>(a, blockIdx.x, gridDim.y, blockIdx.y);
+}
+
+// One launch = the dgrad GEMM of a conv (first nbD * SD workgroups) AND the weight-gradient GEMM that reads the same
+// output gradient (the rest).  The two are independent; launched together they share the chip without a second
+// stream, so the backward chain stays a chain: no fork / join edges (each costs 15-35 us in a replayed hipGraph).
+template <int CTN, int CTM, int CWN, int CWM, bool XF32, int GTN, int GTM, int GWN, int GWM>
+__global__ void __launch_bounds__(256) dual_dgrad_wgrad_bf16_kernel(ConvGemmArgs d, int nbD, int SD, WgradArgs w,
+                                                                    int nbW, int SW) {
+  const int b = blockIdx.x;
+  if (b < nbD * SD) {
+    conv_gemm_bf16_body<CTN, CTM, CWN, CWM, XF32>(d, b % nbD, SD, b / nbD);
+  } else {
+    const int c = b - nbD * SD;
+    wgrad_bf16_body<GTN, GTM, GWN, GWM>(w, c % nbW, SW, c / nbW);
+  }
+}
+
+template <int CTN, int CTM, int CWN, int CWM, bool XF32, int GTN, int GTM, int GWN, int GWM>
+static int launch_dual(const ConvGemmArgs& d, int SD, const WgradArgs& w, int SW, hipStream_t st) {
+  constexpr int BN = 16 * CTN * CWN, BM = 16 * CTM * CWM, BI = 16 * GTN * GWN, BJ = 16 * GTM * GWM;
+  constexpr size_t ldsD = 2 * (BN + BM) * 128, ldsW = 2 * WPX * (wg_stride(BI) + wg_stride(BJ));
+  constexpr size_t lds = ldsD > ldsW ? ldsD : ldsW;
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(dual_dgrad_wgrad_bf16_kernel<CTN, CTM, CWN, CWM, XF32, GTN, GTM, GWN, GWM>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int nbD = ceil_div(d.N, BN) * ceil_div(d.M, BM), nbW = ceil_div(w.NI, BI) * ceil_div(w.J, BJ);
+  prof_scope_begin(NFK_PROF_DUAL_BWD, 2.0 * d.M * (double)d.N * d.K + 2.0 * w.M * (double)w.NI * w.J,
+                   (d.xf32 ? 4.0 : 2.0) * d.M * d.Cin + 2.0 * d.N * d.K + (d.obf16 ? 2.0 : 4.0 * SD) * d.M * d.N +
+                       (w.pbf16 ? 2.0 : 4.0) * w.M * w.NI + (w.qbf16 ? 2.0 : 4.0) * w.M * w.Cq + 4.0 * SW * w.NI * w.J,
+                   st);
+  hipLaunchKernelGGL((dual_dgrad_wgrad_bf16_kernel<CTN, CTM, CWN, CWM, XF32, GTN, GTM, GWN, GWM>),
+                     dim3(nbD * SD + nbW * SW), dim3(256), lds, st, d, nbD, SD, w, nbW, SW);
+  prof_scope_end(NFK_PROF_DUAL_BWD, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+template <int TN, int TM, int WN, int WM>
 static int launch_wgrad_bf16(const WgradArgs& a, int S, hipStream_t st, int cls) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
   constexpr size_t lds = 2 * WPX * (wg_stride(BI) + wg_stride(BJ));
@@ -624,6 +673,48 @@ int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st) {
     case 4: return launch_wgrad_bf16<4, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
     default: return launch_wgrad_bf16<6, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
   }
+}
+
+// dgrad + wgrad of one conv in ONE launch.  Returns NFK_ERR_ARG when the pair of tile configurations the two
+// single launchers would pick is not instantiated (the caller then launches them separately).
+int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
+  d.M = d.B * d.H * d.W;
+  d.K = d.taps * d.Cin;
+  d.nkchunks = ceil_div(d.K, BKH);
+  w.M = w.B * w.H * w.W;
+  w.J = w.taps * w.Cq;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || w.NI <= 0 || w.J <= 0) return NFK_ERR_ARG;
+  if ((long)d.M * d.ldx * 4 >= 0x7fffffffL || (long)d.N * d.Kp * 2 >= 0x7fffffffL) return NFK_ERR_ARG;
+  if ((long)w.M * w.ldp * 4 >= 0x7fffffffL || (long)w.M * w.ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
+  const int SD = conv_splitk_bf16(d.M, d.N, d.K, d.epi);
+  const bool wideD = d.N > 96, bigD = wideD && big_tiles(d.M, d.N), wideW = w.NI > 96;
+  const int ntD = ceil_div(d.N, 16), ntW = ceil_div(w.NI, 16);
+  if (wideD && !wideW) {   // conv3: wide dgrad (fp32 gradient in), narrow weight gradient
+    if (!d.xf32) return NFK_ERR_ARG;
+    if (bigD) {
+      if (ntW == 1) return launch_dual<4, 4, 2, 2, true, 1, 2, 1, 4>(d, SD, w, SW, st);
+      if (ntW == 2) return launch_dual<4, 4, 2, 2, true, 2, 2, 1, 4>(d, SD, w, SW, st);
+      if (ntW == 3) return launch_dual<4, 4, 2, 2, true, 3, 2, 1, 4>(d, SD, w, SW, st);
+    } else {
+      if (ntW == 1) return launch_dual<2, 2, 2, 2, true, 1, 2, 1, 4>(d, SD, w, SW, st);
+      if (ntW == 2) return launch_dual<2, 2, 2, 2, true, 2, 2, 1, 4>(d, SD, w, SW, st);
+      if (ntW == 3) return launch_dual<2, 2, 2, 2, true, 3, 2, 1, 4>(d, SD, w, SW, st);
+    }
+    return NFK_ERR_ARG;
+  }
+  if (wideD && wideW) {    // conv2: bf16 in, both wide
+    if (d.xf32) return NFK_ERR_ARG;
+    return bigD ? launch_dual<4, 4, 2, 2, false, 4, 4, 2, 2>(d, SD, w, SW, st)
+                : launch_dual<2, 2, 2, 2, false, 4, 4, 2, 2>(d, SD, w, SW, st);
+  }
+  if (!wideD && wideW) {   // conv1: narrow dgrad (split-K slabs), wide weight gradient
+    if (d.xf32) return NFK_ERR_ARG;
+    if (ntD == 1) return launch_dual<1, 2, 1, 4, false, 4, 4, 2, 2>(d, SD, w, SW, st);
+    if (ntD == 2) return launch_dual<2, 2, 1, 4, false, 4, 4, 2, 2>(d, SD, w, SW, st);
+    if (ntD == 3) return launch_dual<3, 2, 1, 4, false, 4, 4, 2, 2>(d, SD, w, SW, st);
+    return NFK_ERR_ARG;
+  }
+  return NFK_ERR_ARG;
 }
 
 }  // namespace nfk

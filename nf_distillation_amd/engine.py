@@ -570,6 +570,23 @@ class _EncodeFn(torch.autograd.Function):
         if parts is None or parts.numel() < max(total, 4):
             parts = st["parts"] = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
 
+        # With an auxiliary stream (training.enable_concurrency) and no per-layer gradient hook, the weight-gradient
+        # GEMMs of ALL steps form one chain on that stream, fed by per-step gradient buffers, and are joined once at
+        # the end: the dgrad chain on this stream never waits for them.
+        deferred = bool(lib.nfk_get_aux_stream()) and eng.grad_hook is None
+        ga_off, ga_total, wslab_max = {}, 0, 4
+        if deferred:
+            for r in recs:
+                if r.kind == "step":
+                    ga_off[r.idx] = ga_total
+                    ga_total += _a4(lib.nfk_step2d_bwd_ga_floats(C.byref(r.cs)))
+                    wslab_max = max(wslab_max, lib.nfk_step2d_bwd_wslab_floats(C.byref(r.cs)))
+            ga_all, wslab = st.get("ga_all"), st.get("wslab")
+            if ga_all is None or ga_all.numel() < max(ga_total, 4):
+                ga_all = st["ga_all"] = torch.empty(max(ga_total, 4), device=dev, dtype=torch.float32)
+            if wslab is None or wslab.numel() < wslab_max:
+                wslab = st["wslab"] = torch.empty(wslab_max, device=dev, dtype=torch.float32)
+
         g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
         for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):
             ext = _nhwc(go.to(torch.float32)) if go is not None else None
@@ -587,8 +604,14 @@ class _EncodeFn(torch.autograd.Function):
                 gx = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
                 (ws,) = scratch.get(lib.nfk_step2d_bwd_ws_floats(C.byref(r.cs)))
                 g_main, g_ext = (g, ext) if g is not None else (ext, None)
-                check(lib.nfk_step2d_bwd(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
-                                         ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws), s), "nfk_step2d_bwd")
+                if deferred:
+                    check(lib.nfk_step2d_bwd_deferred(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2),
+                                                      ptr(hs), ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws),
+                                                      ga_all.data_ptr() + 4 * ga_off[r.idx], ptr(wslab), s),
+                          "nfk_step2d_bwd_deferred")
+                else:
+                    check(lib.nfk_step2d_bwd(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
+                                             ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws), s), "nfk_step2d_bwd")
                 g = gx
                 if eng.grad_hook is not None:
                     eng.grad_hook(r.idx)
@@ -619,6 +642,8 @@ class _EncodeFn(torch.autograd.Function):
                     check(lib.nfk_unsqueeze(ptr(tot), ptr(gx), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze")
                     g = gx if not first else gx.permute(0, 3, 1, 2)
 
+        if deferred:
+            check(lib.nfk_aux_join(s), "nfk_aux_join")
         # parameter-side chain for all steps in one launch
         pg = []
         for r in recs:

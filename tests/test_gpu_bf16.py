@@ -125,3 +125,28 @@ def _fused_vs_unfused(name):
         if float(g0[k].abs().max()) > 0:
             assert rel_err(g1[k], g0[k]) < 0.1, (k, rel_err(g1[k], g0[k]))
     assert num / (da ** 0.5 * db ** 0.5) > 0.9995
+
+
+def test_dual_dgrad_wgrad_launch_is_bit_identical():
+    """bf16 backward: a conv's dgrad GEMM and weight-gradient GEMM run as ONE launch (nfk_set_bwd_mode 2, default) or as
+    two (mode 0).  Same tiles, same split-K, same summation order: every gradient must agree bit for bit."""
+    from nf_distillation_amd import capi
+    g = Golden("cifar_k8_full")
+    cfg = g.cfg
+    sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+    h, w, c = cfg["image_shape"]
+    x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 9)
+    res = []
+    try:
+        for mode in (2, 0, 1):
+            capi.lib().nfk_set_bwd_mode(mode)
+            model = build(cfg, sd)
+            outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
+            bpd.mean().backward()
+            torch.cuda.synchronize()
+            res.append({k: p.grad.cpu() for k, p in model.named_parameters()})
+    finally:
+        capi.lib().nfk_set_bwd_mode(2)
+    for other in res[1:]:
+        for k in res[0]:
+            assert torch.equal(res[0][k], other[k]), k
