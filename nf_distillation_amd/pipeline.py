@@ -4,19 +4,24 @@ In the reference's step (pl_module.py:198-382) the critical path is
     teacher forward  ->  loss  ->  student backward  ->  optimiser,
 but the teacher is frozen: its outputs depend only on the batch.  `PipelinedStep` therefore computes the
 teacher's hint tensors for batch t+1 on a side stream while the student runs forward / backward / Adam on
-batch t with the hints produced one call earlier.  Every step still performs exactly the work of the
-reference step, on the same values:
+batch t with the hints produced one call earlier.  Every call still performs exactly the work of one reference
+step (one teacher forward, one student forward + backward, one optimiser step), on the same values:
 
   * batch t+1 is dequantised for the student (x += n_s) and that tensor is kept for the next call, then the
     teacher re-dequantises the same buffer in place (x += n_t), so the teacher still sees student noise +
     its own (models/utils.py:38 + pl_module.py:216-225) and the RNG draws come in the reference's order
     n_s(0), n_t(0), n_s(1), n_t(1), ...
   * the student consumes the hint tensors through static buffers, so the whole call (both branches) can be
-    captured into one hipGraph and replayed.
+    captured into one hipGraph and replayed.  Both branches are plain chains of launches (the backward runs each
+    conv's dgrad and weight-gradient GEMM as one launch), which is what lets them share the chip cleanly: the
+    teacher's deep-level steps fill 16-64 CUs, the student's chain takes the rest.
 
 `training_step(x_next)` trains on the batch given to the PREVIOUS call and returns its losses; `prime(x0)`
 starts the pipeline and `drain()` trains on the last batch.  Results are bit-identical to the sequential
-`DistillationStep` fed with the same noise (tests/test_gpu_training.py).
+`DistillationStep` fed with the same noise (tests/test_gpu_pipeline.py).
+
+Multi-GPU: as in `training.CapturedStep` the collective is never captured: graph A = both branches up to the end
+of the backward, then the eager bucketed all-reduce of the flat gradient arena, then graph B = clip + Adam.
 """
 import torch
 
@@ -24,30 +29,37 @@ from .training import DistillationStep
 
 
 class PipelinedStep:
-    def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2):
+    def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2, with_noise=False):
         if step.teacher is None or step.w_kd <= 0:
             raise ValueError("pipelining needs a teacher with kd_weight > 0")
         self.step = step
-        dev = example_x.device
         self.x_in = torch.empty_like(example_x)        # incoming batch t+1
         self.x_stu_next = torch.empty_like(example_x)  # batch t+1 + student noise (student input of the next call)
         self.x_cur = torch.empty_like(example_x)       # student input of this call
         self.zeros = torch.zeros_like(example_x)       # "noise" for the already dequantised student input
+        # optional caller-supplied dequantisation noise for batch t+1 (parity tests); otherwise drawn on the device
+        self.ns_in = torch.zeros_like(example_x) if with_noise else None
+        self.nt_in = torch.zeros_like(example_x) if with_noise else None
         self.t_next = None   # static hint buffers written by the teacher branch
         self.t_cur = None    # ... and read by the student branch
         self.side = torch.cuda.Stream()
-        self.use_graph = use_graph and step.world == 1
-        self.graph, self.out, self._warm = None, None, warmup
+        self.use_graph = use_graph
+        self.split = step.world > 1
+        if self.split and use_graph:
+            step.set_allreduce_overlap(False)   # graph mode: one all-reduce after the replayed backward
+        self.graph = self.graph_b = None
+        self.out, self._warm = None, warmup
         self.primed = False
 
     # ------------------------------------------------------------------ the two branches
     def _teacher_branch(self):
         """dequantise x_in for the student, keep that copy, run the teacher on the same buffer, keep its hints"""
         st = self.step
-        self.x_in.add_(torch.empty_like(self.x_in).uniform_(0, 1.0 / 256))   # n_s(t+1)
+        n_s = self.ns_in if self.ns_in is not None else torch.empty_like(self.x_in).uniform_(0, 1.0 / 256)
+        self.x_in.add_(n_s)                                                    # n_s(t+1)
         self.x_stu_next.copy_(self.x_in)
         with torch.no_grad():
-            t_z, _, _ = st.teacher(self.x_in, None)                            # adds n_t(t+1) in place
+            t_z, _, _ = st.teacher(self.x_in, None, noise=self.nt_in)          # adds n_t(t+1) in place
         hints = [t_z[i] for i in st.t_idx]
         if self.t_next is None:
             self.t_next = [torch.empty_like(h) for h in hints]
@@ -55,7 +67,7 @@ class PipelinedStep:
         for dst, h in zip(self.t_next, hints):
             dst.copy_(h)
 
-    def _student_branch(self):
+    def _student_fwd_bwd(self):
         st = self.step
         st.flat.zero_grad()
         st.reducer.reset()
@@ -67,16 +79,17 @@ class PipelinedStep:
         kd = kd / max(len(st.s_idx), 1)
         result = (st.w_nll * s_nll + st.w_kd * kd).mean()
         result.backward()
-        st.allreduce()
-        st.optimize()
         return {"nll": s_nll.mean().detach(), "kd": kd.mean().detach(), "result_loss": result.detach()}
 
-    def _body(self):
-        main = torch.cuda.current_stream()
-        # hand over what the previous call prepared
+    def _handover(self):
         for dst, src in zip(self.t_cur, self.t_next):
             dst.copy_(src)
         self.x_cur.copy_(self.x_stu_next)
+
+    def _body_a(self):
+        """both branches up to the end of the backward"""
+        main = torch.cuda.current_stream()
+        self._handover()   # what the previous call prepared
         fork = torch.cuda.Event()
         fork.record(main)
         self.side.wait_event(fork)
@@ -84,22 +97,57 @@ class PipelinedStep:
             self._teacher_branch()
             join = torch.cuda.Event()
             join.record(self.side)
-        out = self._student_branch()
+        out = self._student_fwd_bwd()
         main.wait_event(join)
         return out
 
+    def _body(self):
+        out = self._body_a()
+        self.step.allreduce()
+        self.step.optimize()
+        return out
+
     # ------------------------------------------------------------------ public API
-    def prime(self, x0):
+    def _load(self, x, noise_s, noise_t):
+        self.x_in.copy_(x)
+        if self.ns_in is not None:
+            self.ns_in.copy_(noise_s)
+            self.nt_in.copy_(noise_t)
+
+    def prime(self, x0, noise_s=None, noise_t=None):
         """Start the pipeline with the first batch (runs one teacher forward)."""
-        self.x_in.copy_(x0)
+        self._load(x0, noise_s, noise_t)
         self._teacher_branch()
         self.primed = True
 
-    def training_step(self, x_next):
+    def _capture(self):
+        torch.cuda.synchronize()
+        if not self.split:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.out = self._body()
+            self.graph = g
+            return
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self.out = self._body_a()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self.step.optimize()
+        self.graph, self.graph_b = ga, gb
+
+    def _replay(self):
+        self.graph.replay()
+        if self.split:
+            self.step.reducer.reset()
+            self.step.allreduce()
+            self.graph_b.replay()
+        return self.out
+
+    def training_step(self, x_next, noise_s=None, noise_t=None):
         """Train on the previously supplied batch while the teacher processes `x_next`."""
         if not self.primed:
             raise RuntimeError("call prime(first_batch) first")
-        self.x_in.copy_(x_next)
+        self._load(x_next, noise_s, noise_t)
         if not self.use_graph:
             return self._body()
         if self.graph is None:
@@ -107,30 +155,29 @@ class PipelinedStep:
                 self._warm -= 1
                 return self._body()
             try:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.out = self._body()
-                self.graph = g
+                self._capture()
             except Exception as exc:  # pragma: no cover - depends on the runtime
                 import warnings
                 warnings.warn(f"hipGraph capture of the pipelined step failed ({exc!r}); running eagerly")
                 self.use_graph = False
+                self.graph = self.graph_b = None
+                if self.split:
+                    self.step.set_allreduce_overlap(True)
                 torch.cuda.synchronize()
                 return self._body()
-        self.graph.replay()
-        return self.out
+        return self._replay()
 
-    def prepare(self, x0):
+    def prepare(self, x0, noise_s=None, noise_t=None):
         """prime + eager warm-up + capture, so that no timed call pays for it (consumes warm-up batches = x0)."""
-        self.prime(x0)
+        self.prime(x0, noise_s, noise_t)
         while self.use_graph and self.graph is None:
-            self.training_step(x0)
+            self.training_step(x0, noise_s, noise_t)
 
     def drain(self):
         """Train on the last supplied batch (no new teacher work)."""
-        for dst, src in zip(self.t_cur, self.t_next):
-            dst.copy_(src)
-        self.x_cur.copy_(self.x_stu_next)
+        self._handover()
         self.primed = False
-        return self._student_branch()
+        out = self._student_fwd_bwd()
+        self.step.allreduce()
+        self.step.optimize()
+        return out

@@ -43,8 +43,17 @@ def _worker(rank, world, port, out_dir):
     if os.environ.get("NFK_TEST_GRAPH") == "1":
         from nf_distillation_amd.training import CapturedStep
         runner = CapturedStep(step, x[lo:hi].cuda(), warmup=1, with_noise=True)
-    for _ in range(4):
-        runner.training_step(x[lo:hi].clone().cuda(), ns[lo:hi].cuda(), nt[lo:hi].cuda())
+    xs, nss, nts = x[lo:hi].clone().cuda(), ns[lo:hi].cuda(), nt[lo:hi].cuda()
+    if os.environ.get("NFK_TEST_GRAPH") == "2":   # software-pipelined step, split capture around the all-reduce
+        from nf_distillation_amd.pipeline import PipelinedStep
+        runner = PipelinedStep(step, xs, warmup=1, with_noise=True)
+        runner.prime(xs, nss, nts)
+        for _ in range(3):
+            runner.training_step(xs, nss, nts)
+        runner.drain()
+    else:
+        for _ in range(4):
+            runner.training_step(xs.clone(), nss, nts)
     if runner is not step:
         assert runner.graph is not None and runner.graph_b is not None, "split capture did not happen"
     torch.cuda.synchronize()
@@ -53,12 +62,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", ["eager", "graph"])
+@pytest.mark.parametrize("graph", ["eager", "graph", "pipelined_graph"])
 def test_two_ranks_equal_one_rank(tmp_path, graph):
     from golden_util import Golden
     from nf_distillation_amd.training import DistillationStep
-    port = 29700 + os.getpid() % 1000 + (7 if graph == "graph" else 0)
-    os.environ["NFK_TEST_GRAPH"] = "1" if graph == "graph" else "0"
+    mode = {"eager": 0, "graph": 1, "pipelined_graph": 2}[graph]
+    port = 29700 + os.getpid() % 1000 + 7 * mode
+    os.environ["NFK_TEST_GRAPH"] = str(mode)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     g = Golden("distill8")
     student, teacher = _models(g)
