@@ -96,6 +96,7 @@ def main():
                          "instead of the default software pipeline: teacher forward for batch t+1 beside the "
                          "student's step on batch t (nf_distillation_amd/pipeline.py; same values, every call still "
                          "does one teacher forward + one student forward/backward + one optimiser step)")
+    ap.add_argument("--tuning", type=int, default=None, help="experiment knob: nfk_set_tuning(v)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "
@@ -119,6 +120,8 @@ def main():
     from nf_distillation_amd import capi
     from param_util import synthetic_images
 
+    if args.tuning is not None:
+        capi.lib().nfk_set_tuning(args.tuning)
     student, teacher = make_models(device)
     student.set_compute_dtype(args.dtype)
     teacher.set_compute_dtype(args.dtype)

@@ -234,6 +234,26 @@ int nfk_tab_bwd(const nfk_tab_step *s, const nfk_tab_grads *g, const float *x, c
 /* ---- optimiser (torch.optim.Adam + clip_grad_norm_, pl_module.py:350-354, train.py:46) ------ */
 /* sumsq[0] += sum g^2 over n elements (deterministic two-stage tree); partial: >= 1024 floats */
 int nfk_sumsq(const float *g, size_t n, float *partial, float *sumsq, void *stream);
+
+/* Distillation loss of the hint-MSE + NLL branch of NFModel.loss (pl_module.py:246-300):
+ *   kd[b] = 1/P * sum_p mean_i (s_p[b][i] - t_p[b][i])^2,   result = mean_b (w_nll * nll[b] + w_kd * kd[b]).
+ * s_p / t_p: P pairs of dense per-sample-contiguous tensors with per_sample[p] elements per sample (same memory order
+ * in both).  fwd: part [P][B] scratch, kd_out [B], out3 = {result, mean nll, mean kd}; fixed-order sums.
+ * bwd: g_result is a device scalar; writes g_s[p] (shape of s_p) and g_nll [B] (may be NULL). */
+#define NFK_KD_MAX_PAIRS 8
+typedef struct nfk_kd_pairs {
+  int32_t n, B;
+  const float *s[NFK_KD_MAX_PAIRS], *t[NFK_KD_MAX_PAIRS];
+  int64_t per_sample[NFK_KD_MAX_PAIRS];
+} nfk_kd_pairs;
+typedef struct nfk_kd_grads {
+  float *g_s[NFK_KD_MAX_PAIRS];
+  float *g_nll;
+} nfk_kd_grads;
+int nfk_kd_loss_fwd(const nfk_kd_pairs *pairs, const float *nll, float w_nll, float w_kd, float *part, float *kd_out,
+                    float *out3, void *stream);
+int nfk_kd_loss_bwd(const nfk_kd_pairs *pairs, const float *g_result, float w_nll, float w_kd,
+                    const nfk_kd_grads *grads, void *stream);
 /* p -= lr_t * m_hat / (sqrt(v_hat) + eps) with g scaled by min(1, clip/(sqrt(sumsq)+1e-6)) * gscale */
 int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const float *sumsq, float clip,
                   float gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

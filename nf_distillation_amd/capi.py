@@ -71,6 +71,14 @@ class TabGrads(C.Structure):
     _fields_ = [("gW", c_fp * 6), ("gb", c_fp * 6)]
 
 
+class KdPairs(C.Structure):
+    _fields_ = [("n", C.c_int32), ("B", C.c_int32), ("s", c_fp * 8), ("t", c_fp * 8), ("per_sample", C.c_int64 * 8)]
+
+
+class KdGrads(C.Structure):
+    _fields_ = [("g_s", c_fp * 8), ("g_nll", c_fp)]
+
+
 class RepackDesc(C.Structure):
     _fields_ = [("w", c_fp), ("wt", c_fp), ("wd", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
                 ("taps", C.c_int32), ("frag", C.c_int32), ("wf", c_fp)]
@@ -131,6 +139,8 @@ _PROTOS = {
     "nfk_tab_inv": (i32, [C.POINTER(TabStepC), vp, vp, vp, vp, vp, vp]),
     "nfk_tab_bwd": (i32, [C.POINTER(TabStepC), C.POINTER(TabGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_sumsq": (i32, [vp, u64, vp, vp, vp]),
+    "nfk_kd_loss_fwd": (i32, [C.POINTER(KdPairs), vp, f32, f32, vp, vp, vp, vp]),
+    "nfk_kd_loss_bwd": (i32, [C.POINTER(KdPairs), vp, f32, f32, C.POINTER(KdGrads), vp]),
     "nfk_adam_step": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     "nfk_adam_step_dev": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
 }

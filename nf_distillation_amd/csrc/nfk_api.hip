@@ -16,7 +16,7 @@ int splitk_of(int bf16, int M, int N, int K);
 
 struct StepBwdWs {
   size_t ga3, gz, ga2, ga1, d1slab, col2, col1, tail, wslab, total;
-  int S1, S3w, S2w, S1w, mb;
+  int S1, S3w, S2w, S1w, mb1, mb2;
 };
 StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   StepBwdWs w;
@@ -26,15 +26,17 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   w.S3w = s->bf16 ? wgrad_splits_bf16((int)M, s->Cout, 9 * hid) : wgrad_splits((int)M, s->Cout, 9 * hid);
   w.S2w = s->bf16 ? wgrad_splits_bf16((int)M, hid, hid) : wgrad_splits((int)M, hid, hid);
   w.S1w = s->bf16 ? wgrad_splits_bf16((int)M, hid, 9 * Ch) : wgrad_splits((int)M, hid, 9 * Ch);
-  w.mb = s->bf16 ? conv_mblocks_bf16((int)M, hid) : conv_mblocks((int)M, hid);
+  // column-sum partials of the two dgrad epilogues: one row pair per m-block of THAT launch's tiling
+  w.mb2 = s->bf16 ? conv_mblocks_bf16((int)M, hid, 9 * s->Cout) : conv_mblocks((int)M, hid);   // conv3 dgrad -> col2
+  w.mb1 = s->bf16 ? conv_mblocks_bf16((int)M, hid, hid) : conv_mblocks((int)M, hid);           // conv2 dgrad -> col1
   size_t o = 0;
   w.ga3 = o; o += align4(M * s->Cout);
   w.gz = o; o += align4(M * s->C);
   w.ga2 = o; o += align4(M * hid);
   w.ga1 = o; o += align4(M * hid);
   w.d1slab = o; o += align4((size_t)w.S1 * M * Ch);
-  w.col2 = o; o += align4((size_t)w.mb * 2 * hid);
-  w.col1 = o; o += align4((size_t)w.mb * 2 * hid);
+  w.col2 = o; o += align4((size_t)w.mb2 * 2 * hid);
+  w.col1 = o; o += align4((size_t)w.mb1 * 2 * hid);
   w.tail = o; o += align4((size_t)s->B * 2 * s->Cout);
   size_t ws = (size_t)w.S3w * s->Cout * 9 * hid;
   const size_t ws2 = (size_t)w.S2w * hid * hid, ws1 = (size_t)w.S1w * hid * 9 * Ch;
@@ -81,7 +83,10 @@ void nfk_set_aux_stream(void* stream) {
   }
 }
 
-void nfk_set_tuning(int v) { set_tuning(v); }
+void nfk_set_tuning(int v) {
+  if (v >= 100) set_tuning_bf16(v - 100);   // 100 + n: bf16 128x128 tiles only for K > 64 n  (0: whenever they fill the chip)
+  else set_tuning(v);
+}
 void nfk_profile_begin(void) { prof_begin(); }
 void nfk_profile_end(double* ms, long long* launches, double* flops, double* bytes) {
   prof_end(ms, launches, flops, bytes);
@@ -304,7 +309,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
 
   nfk_small_grad_args sg{};
-  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb; sg.mb2 = L.mb; sg.B = B;
+  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb1; sg.mb2 = L.mb2; sg.B = B;
   sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
   sg.g_l3 = g->g_l3;

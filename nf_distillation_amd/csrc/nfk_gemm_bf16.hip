@@ -17,6 +17,8 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int BKH = 64;                 // bf16 elements per k-chunk
+static int g_wgrad_target_wgs = 768, g_wgrad_max_splits = 64;   // nfk_set_tuning(200 + cap) / (1000 + target)
+static int g_big_tile_min_k = 256;      // see big_tiles(); nfk_set_tuning(100 + v) sets it to v*64 (experiments)
 constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
@@ -379,8 +381,15 @@ int conv_splitk_bf16(int M, int N, int K, int epi) {
   if (S > 16) S = 16;
   return S;
 }
-static bool big_tiles(int M, int N) { return (long)ceil_div(N, 128) * ceil_div(M, 128) >= 256; }
-int conv_mblocks_bf16(int M, int N) { return N > 96 ? ceil_div(M, big_tiles(M, N) ? 128 : 64) : ceil_div(M, 128); }
+// 128x128 tiles only when they still fill the chip AND the k loop is long enough to amortise the tile's prologue and
+// epilogue: a dgrad with K = 9*12 is two k-chunks of pure epilogue, where 64x64 tiles (4x the workgroups, 5 per CU)
+// hide the latency better.
+static bool big_tiles(int M, int N, int K) {
+  return (long)ceil_div(N, 128) * ceil_div(M, 128) >= 256 && K > g_big_tile_min_k;
+}
+int conv_mblocks_bf16(int M, int N, int K) {
+  return N > 96 ? ceil_div(M, big_tiles(M, N, K) ? 128 : 64) : ceil_div(M, 128);
+}
 
 int conv_gemm_bf16(ConvGemmArgs a, hipStream_t st) {
   if (a.taps != 1 && a.taps != 9) return NFK_ERR_ARG;
@@ -393,7 +402,7 @@ int conv_gemm_bf16(ConvGemmArgs a, hipStream_t st) {
   if ((long)a.M * a.ldx * 4 >= 0x7fffffffL || (long)a.N * a.Kp * 2 >= 0x7fffffffL) return NFK_ERR_ARG;
   const int S = conv_splitk_bf16(a.M, a.N, a.K, a.epi);
   if (a.N > 96)
-    return big_tiles(a.M, a.N) ? launch_bf16<4, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128)
+    return big_tiles(a.M, a.N, a.K) ? launch_bf16<4, 4, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE128)
                                : launch_bf16<2, 2, 2, 2>(a, S, st, NFK_PROF_CONV_WIDE64);
   switch (ceil_div(a.N, 16)) {
     case 1: return launch_bf16<1, 2, 1, 4>(a, S, st, NFK_PROF_CONV_NARROW);
@@ -653,10 +662,10 @@ static int launch_wgrad_bf16(const WgradArgs& a, int S, hipStream_t st, int cls)
 int wgrad_splits_bf16(int M, int NI, int J) {
   const int tiles = (NI > 96 ? ceil_div(NI, 128) : 1) * ceil_div(J, 128);
   const int nchunks = ceil_div(M, WPX);
-  int S = ceil_div(768, tiles);
+  int S = ceil_div(g_wgrad_target_wgs, tiles);
   if (S > nchunks / 2) S = nchunks / 2;
   if (S < 1) S = 1;
-  if (S > 64) S = 64;
+  if (S > g_wgrad_max_splits) S = g_wgrad_max_splits;
   return S;
 }
 
@@ -687,7 +696,7 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
   if ((long)d.M * d.ldx * 4 >= 0x7fffffffL || (long)d.N * d.Kp * 2 >= 0x7fffffffL) return NFK_ERR_ARG;
   if ((long)w.M * w.ldp * 4 >= 0x7fffffffL || (long)w.M * w.ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
   const int SD = conv_splitk_bf16(d.M, d.N, d.K, d.epi);
-  const bool wideD = d.N > 96, bigD = wideD && big_tiles(d.M, d.N), wideW = w.NI > 96;
+  const bool wideD = d.N > 96, bigD = wideD && big_tiles(d.M, d.N, d.K), wideW = w.NI > 96;
   const int ntD = ceil_div(d.N, 16), ntW = ceil_div(w.NI, 16);
   if (wideD && !wideW) {   // conv3: wide dgrad (fp32 gradient in), narrow weight gradient
     if (!d.xf32) return NFK_ERR_ARG;
@@ -715,6 +724,12 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
     return NFK_ERR_ARG;
   }
   return NFK_ERR_ARG;
+}
+
+void set_tuning_bf16(int v) {
+  if (v >= 900) g_wgrad_target_wgs = v - 900;
+  else if (v >= 100) g_wgrad_max_splits = v - 100;
+  else g_big_tile_min_k = v * 64;
 }
 
 }  // namespace nfk

@@ -133,7 +133,8 @@ int conv_gemm(ConvGemmArgs a, hipStream_t st);
 int conv_gemm_bf16(ConvGemmArgs a, hipStream_t st);
 int padded_k_bf16(int K);
 int conv_splitk_bf16(int M, int N, int K, int epi);
-int conv_mblocks_bf16(int M, int N);
+int conv_mblocks_bf16(int M, int N, int K);
+void set_tuning_bf16(int v);
 int wgrad_splits_bf16(int M, int NI, int J);
 int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st);
 int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st);  // NFK_ERR_ARG: pair not instantiated

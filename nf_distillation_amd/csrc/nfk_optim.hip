@@ -65,6 +65,58 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 }  // namespace nfk
 
 using namespace nfk;
+// ------------------------------------------------------------------------------------------
+// Distillation loss (NFModel.loss, pl_module.py:246-300 for the hint-MSE + NLL branch):
+//   kd[b] = 1/P * sum_p mean_i (s_p[b][i] - t_p[b][i])^2 ,  result = mean_b (w_nll * nll[b] + w_kd * kd[b])
+// two launches forward (per (sample, pair) sums, then one workgroup combines in fixed order), one backward.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kd_pair_sums_kernel(nfk_kd_pairs a, float* __restrict__ part) {
+  __shared__ float sh[32];
+  const int b = blockIdx.x, p = blockIdx.y;
+  const long n = a.per_sample[p];
+  const float* s = a.s[p] + (long)b * n;
+  const float* t = a.t[p] + (long)b * n;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const float d = s[i] - t[i];
+    acc += d * d;
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[p * a.B + b] = acc / (float)n;
+}
+__global__ void __launch_bounds__(256) kd_combine_kernel(nfk_kd_pairs a, const float* __restrict__ part,
+                                                         const float* __restrict__ nll, float w_nll, float w_kd,
+                                                         float* __restrict__ kd_out, float* __restrict__ out3) {
+  __shared__ float sh[32];
+  float r = 0.f, sn = 0.f, sk = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    float kd = 0.f;
+    for (int p = 0; p < a.n; ++p) kd += part[p * a.B + b];
+    kd /= (float)(a.n > 0 ? a.n : 1);
+    kd_out[b] = kd;
+    r += w_nll * nll[b] + w_kd * kd;
+    sn += nll[b];
+    sk += kd;
+  }
+  r = block_sum(r, sh);
+  sn = block_sum(sn, sh);
+  sk = block_sum(sk, sh);
+  if (threadIdx.x == 0) { out3[0] = r / a.B; out3[1] = sn / a.B; out3[2] = sk / a.B; }
+}
+// g_s[p][b][i] = g_result * w_kd * 2 / (B * P * n_p) * (s - t) ;  g_nll[b] = g_result * w_nll / B
+__global__ void __launch_bounds__(256) kd_bwd_kernel(nfk_kd_pairs a, const float* __restrict__ g_result, float w_nll,
+                                                     float w_kd, nfk_kd_grads g) {
+  const int b = blockIdx.x, p = blockIdx.y;
+  const float gr = g_result[0];
+  if (p == 0 && threadIdx.x == 0 && g.g_nll) g.g_nll[b] = gr * w_nll / (float)a.B;
+  const long n = a.per_sample[p];
+  const float coef = gr * w_kd * 2.f / ((float)a.B * (float)a.n * (float)n);
+  const float* s = a.s[p] + (long)b * n;
+  const float* t = a.t[p] + (long)b * n;
+  float* o = g.g_s[p] + (long)b * n;
+  for (long i = threadIdx.x; i < n; i += 256) o[i] = coef * (s[i] - t[i]);
+}
+
 extern "C" {
 int nfk_sumsq(const float* g, size_t n, float* partial, float* sumsq, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -102,6 +154,26 @@ int nfk_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, co
                      beta2, 1.f, eps, weight_decay, (const int*)step_dev);
   NFK_LAUNCH_CHECK();
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_kd_loss_fwd(const nfk_kd_pairs* pairs, const float* nll, float w_nll, float w_kd, float* part, float* kd_out,
+                    float* out3, void* stream) {
+  if (pairs->B <= 0 || pairs->n < 0 || pairs->n > NFK_KD_MAX_PAIRS) return NFK_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (pairs->n > 0) {
+    hipLaunchKernelGGL(kd_pair_sums_kernel, dim3(pairs->B, pairs->n), dim3(256), 0, st, *pairs, part);
+    NFK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(kd_combine_kernel, dim3(1), dim3(256), 0, st, *pairs, part, nll, w_nll, w_kd, kd_out, out3);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_kd_loss_bwd(const nfk_kd_pairs* pairs, const float* g_result, float w_nll, float w_kd,
+                    const nfk_kd_grads* grads, void* stream) {
+  if (pairs->B <= 0 || pairs->n <= 0 || pairs->n > NFK_KD_MAX_PAIRS) return NFK_ERR_ARG;
+  hipLaunchKernelGGL(kd_bwd_kernel, dim3(pairs->B, pairs->n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     *pairs, g_result, w_nll, w_kd, *grads);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

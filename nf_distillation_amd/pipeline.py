@@ -25,7 +25,7 @@ of the backward, then the eager bucketed all-reduce of the flat gradient arena, 
 """
 import torch
 
-from .training import DistillationStep
+from .training import DistillationStep, distillation_loss
 
 
 class PipelinedStep:
@@ -72,14 +72,9 @@ class PipelinedStep:
         st.flat.zero_grad()
         st.reducer.reset()
         s_z, s_nll, _ = st.student(self.x_cur, None, noise=self.zeros)
-        kd = None
-        for si, tz in zip(st.s_idx, self.t_cur):
-            d = (s_z[si] - tz).square().flatten(1).mean(1)
-            kd = d if kd is None else kd + d
-        kd = kd / max(len(st.s_idx), 1)
-        result = (st.w_nll * s_nll + st.w_kd * kd).mean()
-        result.backward()
-        return {"nll": s_nll.mean().detach(), "kd": kd.mean().detach(), "result_loss": result.detach()}
+        out = distillation_loss(s_nll, [s_z[i] for i in st.s_idx], self.t_cur, st.w_nll, st.w_kd)
+        out["result_loss"].backward()
+        return {k: v.detach() for k, v in out.items()}
 
     def _handover(self):
         for dst, src in zip(self.t_cur, self.t_next):

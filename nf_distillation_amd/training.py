@@ -11,6 +11,8 @@ Restates, for the hot path only, what ``pl_module.NFModel`` + ``pl.Trainer`` do 
 with the student's parameters and gradients re-homed into flat fp32 arenas so that clipping,
 Adam and the RCCL gradient all-reduce each touch ONE contiguous buffer.
 """
+import ctypes as C
+
 import torch
 
 from . import capi
@@ -118,6 +120,70 @@ class FlatAdam:
         return torch.sqrt(self.sumsq[0]) * self.grad_scale
 
 
+def _dense_pair(s, t):
+    """(s, t) hint tensors must be dense, same shape and same memory order (both are channels-last views of the
+    engine's NHWC buffers, or both contiguous)."""
+    if s.shape != t.shape or s.stride() != t.stride() or s.dtype != torch.float32 or t.dtype != torch.float32:
+        raise ValueError("hint tensors must be fp32 with identical shapes and strides")
+    B = s.shape[0]
+    per = s.numel() // max(B, 1)
+    dense = s.is_contiguous() or (s.dim() == 4 and s.is_contiguous(memory_format=torch.channels_last))
+    if not dense or (B > 1 and s.stride(0) != per):
+        raise ValueError("hint tensors must be dense and per-sample contiguous")
+    return per
+
+
+class _KdLossFn(torch.autograd.Function):
+    """result = mean_b(w_nll * nll[b] + w_kd * kd[b]),  kd[b] = mean over hint pairs of the per-sample MSE
+    (NFModel.loss, pl_module.py:246-300) -- two launches forward, one backward (nfk_kd_loss_fwd / _bwd) instead of
+    the ~45 elementwise / reduction kernels the same expression costs as tensor ops."""
+
+    @staticmethod
+    def forward(ctx, s_nll, w_nll, w_kd, n_pairs, *tensors):
+        s_list, t_list = tensors[:n_pairs], tensors[n_pairs:]
+        capi.require_cuda(s_nll, "s_nll")
+        B = s_nll.shape[0]
+        pairs = capi.KdPairs()
+        pairs.n, pairs.B = n_pairs, B
+        for i, (s, t) in enumerate(zip(s_list, t_list)):
+            pairs.per_sample[i] = _dense_pair(s, t)
+            pairs.s[i], pairs.t[i] = s.data_ptr(), t.data_ptr()
+        nll = s_nll.detach().to(torch.float32).contiguous()
+        part = torch.empty(max(n_pairs, 1) * B, device=nll.device, dtype=torch.float32)
+        kd = torch.empty(B, device=nll.device, dtype=torch.float32)
+        out3 = torch.empty(3, device=nll.device, dtype=torch.float32)
+        capi.check(capi.lib().nfk_kd_loss_fwd(C.byref(pairs), capi.ptr(nll), float(w_nll), float(w_kd), capi.ptr(part),
+                                              capi.ptr(kd), capi.ptr(out3), capi.stream()), "nfk_kd_loss_fwd")
+        ctx.pairs, ctx.w = pairs, (float(w_nll), float(w_kd))
+        ctx.keep = (s_list, t_list, nll)
+        ctx.n_pairs = n_pairs
+        ctx.mark_non_differentiable(kd)
+        return out3[0], out3[1].detach(), out3[2].detach(), kd
+
+    @staticmethod
+    def backward(ctx, g_result, _g1, _g2, _g3):
+        s_list, _, nll = ctx.keep
+        g = g_result.detach().to(torch.float32).reshape(1).contiguous()
+        grads = capi.KdGrads()
+        g_s = [torch.empty_like(s) for s in s_list]   # preserves the (channels-last) strides
+        for i, t in enumerate(g_s):
+            grads.g_s[i] = t.data_ptr()
+        g_nll = torch.empty_like(nll)
+        grads.g_nll = g_nll.data_ptr()
+        if ctx.n_pairs > 0:
+            capi.check(capi.lib().nfk_kd_loss_bwd(C.byref(ctx.pairs), capi.ptr(g), ctx.w[0], ctx.w[1], C.byref(grads),
+                                                  capi.stream()), "nfk_kd_loss_bwd")
+        else:
+            g_nll = g * (ctx.w[0] / nll.shape[0]) * torch.ones_like(nll)
+        return (g_nll, None, None, None) + tuple(g_s) + (None,) * len(g_s)
+
+
+def distillation_loss(s_nll, s_hints, t_hints, w_nll, w_kd):
+    """-> dict(nll, kd, result_loss) as NFModel.loss logs them; only result_loss carries a gradient."""
+    result, nll_m, kd_m, _ = _KdLossFn.apply(s_nll, w_nll, w_kd, len(s_hints), *s_hints, *[t.detach() for t in t_hints])
+    return {"nll": nll_m, "kd": kd_m, "result_loss": result}
+
+
 class DistillationStep:
     """One optimisation step of teacher->student distillation (see module docstring)."""
 
@@ -187,16 +253,10 @@ class DistillationStep:
             s_z, s_nll, _ = self.student(x, None, noise=noise_student)
             if use_teacher:
                 t_z = self._teacher_forward(x, noise_teacher)
-        kd = None
         if use_teacher:
-            for si, ti in zip(self.s_idx, self.t_idx):
-                d = (s_z[si] - t_z[ti]).square().flatten(1).mean(1)
-                kd = d if kd is None else kd + d
-            kd = kd / max(len(self.s_idx), 1)
-        else:
-            kd = torch.zeros((), device=x.device)
-        result = (self.w_nll * s_nll + self.w_kd * kd).mean()
-        return {"nll": s_nll.mean(), "kd": kd.mean(), "result_loss": result}
+            return distillation_loss(s_nll, [s_z[i] for i in self.s_idx], [t_z[i] for i in self.t_idx],
+                                     self.w_nll, self.w_kd)
+        return distillation_loss(s_nll, [], [], self.w_nll, 0.0)
 
     # A step = three phases; multi-rank graph replay captures the first and the last separately so that the
     # collective itself is never part of a captured graph.
