@@ -20,6 +20,7 @@ namespace nfk {
 // ==========================================================================================
 // small dense helpers on global scratch, executed by ONE workgroup
 // ==========================================================================================
+constexpr size_t PREP_LDS = 60 * 1024, PREP_BWD_LDS = 60 * 1024;   // dynamic LDS of prep_kernel / prep_bwd_kernel
 // C[n][n] = A * B   (opA/opB: 0 = as is, 1 = transposed)
 __device__ void blk_matmul(const float* A, int ta, const float* B, int tb, float* C, int n) {
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
@@ -110,13 +111,21 @@ __device__ void build_W(const PrepDesc& d, float* W, float* T0, float* T1, float
 
 __global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ descs, int want_inverse) {
   __shared__ float sh[32];
-  const PrepDesc d = descs[blockIdx.x];
+  PrepDesc d = descs[blockIdx.x];
   const int C = d.C, CC = C * C;
-  float* W = d.scratch;
+  // work matrices (and P) in LDS when six C x C matrices fit the 60 KiB of the launch, else in the step's scratch
+  extern __shared__ __attribute__((aligned(16))) float pf_lds[];
+  const bool in_lds = (size_t)6 * CC * sizeof(float) <= PREP_LDS;
+  float* W = in_lds ? pf_lds : d.scratch;
   float* T0 = W + CC;
   float* T1 = T0 + CC;
   float* AUG = T1 + CC;
   if (C > 0) {
+  if (in_lds && d.perm_kind == PERM_LU) {
+    float* Pl = W + 5 * CC;
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];
+    d.p = Pl;   // build_W's first barrier comes before its first use
+  }
   build_W(d, W, T0, T1, sh);
 
   // sums of logs / log_s
@@ -174,7 +183,7 @@ __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __rest
   part[e] = slab_sum(part, g.nparts, E, e);
 }
 
-constexpr size_t PREP_BWD_LDS = 60 * 1024;
+
 // Backward of prep: chain (gWf, gcf, G = sum_b g_logdet[b]) to the raw parameters; accumulates.
 //   part: [nparts][C*C + C] partial sums of  gWf[o][c] = sum_m gz[m][o] x[m][c],  gcf[o] = sum_m gz[m][o]
 __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
@@ -733,7 +742,7 @@ static inline int sample_threads(int n) { return n >= 1024 ? 1024 : (n > 256 ? (
 
 int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st) {
   if (nsteps <= 0) return NFK_OK;
-  hipLaunchKernelGGL(prep_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, want_inverse);
+  hipLaunchKernelGGL(prep_kernel, dim3(nsteps), dim3(256), PREP_LDS, st, descs_dev, want_inverse);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

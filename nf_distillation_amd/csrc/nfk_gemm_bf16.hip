@@ -300,45 +300,57 @@ __global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
 }
 
 // conv.weight [Cout][Cin][taps] (fp32) -> bf16 wt [Cout][Kp64] and wd [Cin][Kp64(taps*Cout)] (flipped taps)
-__global__ void repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ descs) {
+__global__ void __launch_bounds__(256) repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ descs) {
+  // one thread = 8 consecutive output elements (one 16-byte store); 32-bit index math, one division per 8 elements
   const nfk_repack_desc d = descs[blockIdx.y];
-  const int Kp = (d.taps * d.Cin + BKH - 1) / BKH * BKH, Kpd = (d.taps * d.Cout + BKH - 1) / BKH * BKH;
-  const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
+  const int K = d.taps * d.Cin, Kd = d.taps * d.Cout;
+  const int Kp = (K + BKH - 1) / BKH * BKH, Kpd = (Kd + BKH - 1) / BKH * BKH;
   const int rows_g = (d.frag == 1) ? d.Cout : (d.Cout + 15) / 16 * 16;
-  const long total_g = (d.wf && d.frag) ? (long)rows_g * Kp : 0;
+  const int n8_f = d.Cout * (Kp / 8), n8_d = d.wd ? d.Cin * (Kpd / 8) : 0;
+  const int n8_g = (d.wf && d.frag) ? rows_g * (Kp / 8) : 0;
   __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
-  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d + total_g;
-       t += (long)gridDim.x * blockDim.x) {
-    if (t >= total_f + total_d) {
-      // fragment order: element e of lane `lane` of the A operand of k-step ks of row tile nt
-      const long u = t - total_f - total_d;
-      const int e = u & 7, lane = (u >> 3) & 63;
-      const long fr = u >> 9;
-      int co, k;
-      if (d.frag == 1) {   // 32x32x16: 32 rows x 16 k per fragment
-        const int KS = Kp / 16, nt = fr / KS, ks = fr - (long)nt * KS;
-        co = nt * 32 + (lane & 31); k = ks * 16 + (lane >> 5) * 8 + e;
-      } else {             // 16x16x32: 16 rows x 32 k per fragment
-        const int KS = Kp / 32, nt = fr / KS, ks = fr - (long)nt * KS;
-        co = nt * 16 + (lane & 15); k = ks * 32 + (lane >> 4) * 8 + e;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < n8_f + n8_d + n8_g; t += gridDim.x * 256) {
+    float v[8];
+    __bf16* dst;
+    if (t < n8_f + n8_g) {
+      // forward layouts: value(co, k) = w[co][k % Cin][k / Cin], zero outside
+      int co, k0;
+      if (t < n8_f) {                       // row-major [Cout][Kp]
+        co = t / (Kp / 8); k0 = (t - co * (Kp / 8)) * 8;
+        dst = wt + (long)t * 8;
+      } else {                              // fragment order: 8 elements of lane `lane` of fragment `fr`
+        const int u = t - n8_f, lane = u & 63, fr = u >> 6;
+        if (d.frag == 1) {                  // 32x32x16 A fragments: 32 rows x 16 k
+          const int KS = Kp / 16, nt = fr / KS, ks = fr - nt * KS;
+          co = nt * 32 + (lane & 31); k0 = ks * 16 + (lane >> 5) * 8;
+        } else {                            // 16x16x32 A fragments: 16 rows x 32 k
+          const int KS = Kp / 32, nt = fr / KS, ks = fr - nt * KS;
+          co = nt * 16 + (lane & 15); k0 = ks * 32 + (lane >> 4) * 8;
+        }
+        dst = wf + (long)u * 8;
       }
-      float v = 0.f;
-      if (co < d.Cout && k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];
-      wf[u] = (__bf16)v;
-    } else if (t < total_f) {
-      const int co = t / Kp, k = t % Kp;
-      float v = 0.f;
-      if (k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];
-      wt[t] = (__bf16)v;
+      int tap = k0 / d.Cin, ci = k0 - tap * d.Cin;
+      const float* wrow = d.w + (long)co * d.Cin * d.taps;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = (co < d.Cout && k0 + e < K) ? wrow[ci * d.taps + tap] : 0.f;
+        if (++ci == d.Cin) { ci = 0; ++tap; }
+      }
     } else {
-      const long u = t - total_f;
-      const int ci = u / Kpd, k = u % Kpd;
-      float v = 0.f;
-      if (k < d.taps * d.Cout) v = d.w[((long)(k % d.Cout) * d.Cin + ci) * d.taps + (d.taps - 1 - k / d.Cout)];
-      wd[u] = (__bf16)v;
+      // dgrad layout [Cin][Kpd]: value(ci, k) = w[k % Cout][ci][taps - 1 - k / Cout]
+      const int u = t - n8_f - n8_g, ci = u / (Kpd / 8), k0 = (u - ci * (Kpd / 8)) * 8;
+      int tap = k0 / d.Cout, co = k0 - tap * d.Cout;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = (k0 + e < Kd) ? d.w[((long)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)] : 0.f;
+        if (++co == d.Cout) { co = 0; ++tap; }
+      }
+      dst = wd + (long)u * 8;
     }
+    const u32x4b pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    *reinterpret_cast<u32x4b*>(dst) = pk;
   }
 }
 
