@@ -17,6 +17,7 @@ int splitk_of(int bf16, int M, int N, int K);
 struct StepBwdWs {
   size_t ga3, gz, ga2, ga1, d1slab, col2, col1, tail, wslab, total;
   int S1, S3w, S2w, S1w, mb1, mb2;
+  size_t ws3, ws2;   // sizes of the first two weight-gradient slab regions inside wslab
 };
 StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   StepBwdWs w;
@@ -38,11 +39,10 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   w.col2 = o; o += align4((size_t)w.mb2 * 2 * hid);
   w.col1 = o; o += align4((size_t)w.mb1 * 2 * hid);
   w.tail = o; o += align4((size_t)s->B * 2 * s->Cout);
-  size_t ws = (size_t)w.S3w * s->Cout * 9 * hid;
-  const size_t ws2 = (size_t)w.S2w * hid * hid, ws1 = (size_t)w.S1w * hid * 9 * Ch;
-  if (ws2 > ws) ws = ws2;
-  if (ws1 > ws) ws = ws1;
-  w.wslab = o; o += align4(ws);
+  // the three weight gradients' split slabs, each in a region of its own (reduced together by step_tail_kernel)
+  w.ws3 = align4((size_t)w.S3w * s->Cout * 9 * hid);
+  w.ws2 = align4((size_t)w.S2w * hid * hid);
+  w.wslab = o; o += w.ws3 + w.ws2 + align4((size_t)w.S1w * hid * 9 * Ch);
   w.total = o;
   return w;
 }
@@ -269,16 +269,22 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   hipStream_t ws_st = st;  // stream of the wgrad GEMMs
   const bool use_aux = !dual && g_aux && g_aux != st;
   if (use_aux) ws_st = g_aux;
-  int fork_i = 0;
+  int fork_i = 0, conv_i = 0;
+  StepTailArgs tail_f{};   // slab reductions deferred to the one launch at the end of the step (dual mode)
   auto conv_bwd = [&](const ConvGemmArgs& dg, const WgradArgs& wg, int Sw, int Co, int Ci, int taps, float* gw) -> int {
+    const int k = conv_i++;
     if (dual) {
       const int rc = dual_dgrad_wgrad_bf16(dg, wg, Sw, st);
-      if (rc == NFK_OK) return wgrad_finalize(wslab, Sw, wg.slab_stride, Co, Ci, taps, gw, st);
+      if (rc == NFK_OK) {
+        tail_f.slabs[k] = wg.out; tail_f.gradW[k] = gw; tail_f.stride[k] = wg.slab_stride;
+        tail_f.S[k] = Sw; tail_f.Cout[k] = Co; tail_f.Cin[k] = Ci; tail_f.taps[k] = taps;
+        return NFK_OK;
+      }
       if (rc != NFK_ERR_ARG) return rc;   // NFK_ERR_ARG: this pair of tile shapes is not instantiated
     }
     if (use_aux) fork_to_aux(st, fork_i++);
     NFK_TRY(bf ? wgrad_gemm_bf16(wg, Sw, ws_st) : wgrad_gemm(wg, Sw, ws_st));
-    NFK_TRY(wgrad_finalize(wslab, Sw, wg.slab_stride, Co, Ci, taps, gw, ws_st));
+    NFK_TRY(wgrad_finalize(wg.out, Sw, wg.slab_stride, Co, Ci, taps, gw, ws_st));
     return run_conv(bf, dg, st);
   };
 
@@ -294,7 +300,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   // conv2 (block.2)
   WgradArgs w2{};
   w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
-  w2.B = B; w2.H = H; w2.W = W; w2.out = wslab; w2.slab_stride = (long)hid * hid;
+  w2.B = B; w2.H = H; w2.W = W; w2.out = wslab + L.ws3; w2.slab_stride = (long)hid * hid;
   w2.pbf16 = bf; w2.qbf16 = bf;
   ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
   d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
@@ -303,7 +309,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   // conv1 (block.0)
   WgradArgs w1{};
   w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = z; w1.ldq = C; w1.Cq = Ch; w1.taps = 9;
-  w1.B = B; w1.H = H; w1.W = W; w1.out = wslab; w1.slab_stride = (long)hid * 9 * Ch;
+  w1.B = B; w1.H = H; w1.W = W; w1.out = wslab + L.ws3 + L.ws2; w1.slab_stride = (long)hid * 9 * Ch;
   w1.pbf16 = bf;
   ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
   NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
@@ -313,7 +319,8 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
   sg.g_l3 = g->g_l3;
-  NFK_TRY(launch_small_grads(sg, st));
+  if (tail_f.S[0] | tail_f.S[1] | tail_f.S[2]) NFK_TRY(launch_step_tail(sg, tail_f, st));
+  else NFK_TRY(launch_small_grads(sg, st));
 
   // actnorm + permutation backward: g_x = Wf^T g_z, partial (gWf, gcf) for nfk_prep_bwd
   ChanMixArgs m{};

@@ -729,6 +729,50 @@ __global__ void __launch_bounds__(256) small_grads_kernel(SmallGradArgs a) {
   }
 }
 
+// One launch for everything a FlowStep's backward still owes its parameters once the GEMMs are done: the three
+// split-slab reductions of the weight gradients (wgrad finalize: gradW[co][ci][tap] += sum_s slab[s][co][tap*Cin+ci])
+// and the small per-channel gradients above.  blockIdx.x ranges select the task.
+__global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTailArgs f) {
+  const int nsg = f.sg_blocks * 3;
+  if ((int)blockIdx.x < nsg) {
+    __shared__ float red[2][8][32];
+    const int seg = blockIdx.x / f.sg_blocks, bx = blockIdx.x - seg * f.sg_blocks;
+    const float* src; int rows, n; float *g0, *g1;
+    if (seg == 0) { src = a.col1; rows = a.mb1; n = a.n1; g0 = a.g_l1; g1 = a.g_b1; }
+    else if (seg == 1) { src = a.col2; rows = a.mb2; n = a.n2; g0 = a.g_l2; g1 = a.g_b2; }
+    else { src = a.tail; rows = a.B; n = a.n3; g0 = a.g_bias3; g1 = a.g_l3; }
+    const int col = bx * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    if (bx * 32 >= n) return;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < n)
+      for (int i = rg; i < rows; i += 8) {
+        s0 += src[((long)i * 2) * n + col];
+        s1 += src[((long)i * 2 + 1) * n + col];
+      }
+    red[0][rg][threadIdx.x & 31] = s0;
+    red[1][rg][threadIdx.x & 31] = s1;
+    __syncthreads();
+    if (rg < 2 && col < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[rg][k][threadIdx.x & 31];
+      (rg == 0 ? g0 : g1)[col] += t;
+    }
+    return;
+  }
+  int b = blockIdx.x - nsg, k = 0;
+  while (k < 2 && b >= f.blocks[k]) { b -= f.blocks[k]; ++k; }
+  const int S = f.S[k], Cin = f.Cin[k], taps = f.taps[k], J = Cin * taps;
+  const int total = f.Cout[k] * J;
+  const float* slabs = f.slabs[k];
+  float* gw = f.gradW[k];
+  for (int t = b * 256 + threadIdx.x; t < total; t += f.blocks[k] * 256) {
+    const int r = t / taps, tap = t - r * taps;
+    const int co = r / Cin, ci = r - co * Cin;
+    gw[t] += slab_sum(slabs, S, f.stride[k], (long)co * J + tap * Cin + ci);
+  }
+}
+
 // ==========================================================================================
 // host launchers
 // ==========================================================================================
@@ -869,6 +913,23 @@ int launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
   if (a.n3 > n) n = a.n3;
   if (n <= 0) return NFK_OK;
   hipLaunchKernelGGL(small_grads_kernel, dim3(ceil_div(n, 32), 3), dim3(256), 0, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st) {
+  int n = a.n1 > a.n2 ? a.n1 : a.n2;
+  if (a.n3 > n) n = a.n3;
+  f.sg_blocks = ceil_div(n > 0 ? n : 1, 32);
+  int total = f.sg_blocks * 3;
+  for (int k = 0; k < 3; ++k) {
+    const long e = (long)f.Cout[k] * f.Cin[k] * f.taps[k];
+    int b = f.S[k] > 0 ? (int)((e + 255) / 256) : 0;
+    if (b > 1024) b = 1024;
+    f.blocks[k] = b;
+    total += b;
+  }
+  hipLaunchKernelGGL(step_tail_kernel, dim3(total), dim3(256), 0, st, a, f);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

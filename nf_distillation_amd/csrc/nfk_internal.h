@@ -166,5 +166,13 @@ int launch_add_slabs(const float* g, int ldg, const float* gext, int ldge, const
 int launch_prior_fwd(const PriorArgs& a, int B, hipStream_t st);
 int launch_prior_bwd(const PriorBwdArgs& a, int B, hipStream_t st);
 int launch_small_grads(const SmallGradArgs& a, hipStream_t st);
+// three weight-gradient slab reductions (S[k] == 0: none) + the small per-channel gradients in one launch
+struct StepTailArgs {
+  const float* slabs[3]; float* gradW[3];
+  long stride[3];
+  int S[3], Cout[3], Cin[3], taps[3];
+  int blocks[3], sg_blocks;   // filled by the launcher
+};
+int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st);
 
 }  // namespace nfk
