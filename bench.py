@@ -204,8 +204,12 @@ def main():
                                          "schedule": "hipGraph replay, teacher and student of the same batch per call"}
 
     if rank == 0 and world == 1 and not args.no_roofline:
+        # HIP events bracket each launch: eager steps (outside the captured graph), on ONE stream, so that a launch's
+        # duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r01_d_*)
+        step.enable_concurrency(False)
+        run(2, eager=True)
         capi.profile_begin()
-        run(args.steps, eager=True)  # HIP events bracket each launch: outside the captured graph
+        run(args.steps, eager=True)
         prof = capi.profile_end()
         dom = max(prof, key=lambda d: d["ms"])
         n = max(dom["launches"], 1)

@@ -266,9 +266,11 @@ int nfk_adam_step(float *p, const float *g, float *m, float *v, size_t n, const 
  * NFK_PROF_CLASSES. */
 enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW = 2, NFK_PROF_WGRAD_WIDE = 3,
        NFK_PROF_WGRAD_NARROW = 4,
-       NFK_PROF_FUSED_STEP = 5, /* nfk_step2d_fwd_fused: flops of the three convs, bytes = x + z + weights (+ saves) */
-       NFK_PROF_DUAL_BWD = 6,   /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode) */
-       NFK_PROF_CLASSES = 7 };
+       /* nfk_step2d_fwd_fused by conv3 width (one template instance each for Glow's shapes: CIFAR levels 1 / 2 / 3):
+        * flops of the three convs, bytes = x + z + weights (+ what a training forward saves) */
+       NFK_PROF_FUSED_STEP = 5, NFK_PROF_FUSED_STEP_NT2 = 6, NFK_PROF_FUSED_STEP_NT3 = 7,
+       NFK_PROF_DUAL_BWD = 8,   /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode) */
+       NFK_PROF_CLASSES = 9 };
 void nfk_profile_begin(void);
 /* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
  * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */

@@ -166,7 +166,10 @@ def lib():
 
 PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
                 "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>",
-                "fused_step_fwd_kernel (whole FlowStep forward)", "dual_dgrad_wgrad_bf16_kernel (dgrad + wgrad)")
+                "fused2_step_fwd_kernel<*,1,*> (FlowStep forward, Cout <= 16: CIFAR level 1 = <3,1,4>)",
+                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8>)",
+                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <2,3,16>)",
+                "dual_dgrad_wgrad_bf16_kernel (dgrad + wgrad)")
 
 
 def profile_begin():

@@ -567,9 +567,11 @@ int nfk_step2d_fwd_fused(const nfk_step2d* s, const float* x, int ldx, float* zs
   if (h2save) bytes += 2.0 * M * hid;
   if (hsave) bytes += 4.0 * M * s->Cout;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  prof_scope_begin(NFK_PROF_FUSED_STEP, flops, bytes, st);
+  int cls = NFK_PROF_FUSED_STEP + (s->Cout + 15) / 16 - 1;
+  if (cls > NFK_PROF_FUSED_STEP_NT3) cls = NFK_PROF_FUSED_STEP_NT3;
+  prof_scope_begin(cls, flops, bytes, st);
   const int rc = step2d_fwd_fused_impl(s, x, ldx, zsave, h1save, h2save, hsave, zout, ldpart, stream);
-  prof_scope_end(NFK_PROF_FUSED_STEP, st);
+  prof_scope_end(cls, st);
   return rc;
 }
 

@@ -456,7 +456,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int c0, 
 }
 
 template <int TN, int TM, int WN, int WM>
-__device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, const int S, const int z) {
+__device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, const int S, const int z_in) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
   constexpr int SP = wg_stride(BI), SQ = wg_stride(BJ);
   constexpr int STAGE = WPX * (SP + SQ);
@@ -466,7 +466,12 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid % WN, wm = wid / WN;
   const int nIB = (a.NI + BI - 1) / BI, nJB = (a.J + BJ - 1) / BJ;
-  const int bid = xcd_remap_b(bx, nIB * nJB);
+  // All tiles of one split read the same pixel range of P and Q: the remap runs over (split, tile) so that they land
+  // on ONE XCD and share its L2 (remapping the tiles of each split alone spreads every pixel range over all 8 L2s:
+  // 231 MB of HBM traffic per level-1 conv2 launch against 133 MB algorithmic, profiles/r01_d_pmc_traffic_bf16.json).
+  const int nT = nIB * nJB;
+  const int lin = xcd_remap_b(z_in * nT + bx, nT * S);
+  const int z = lin / nT, bid = lin - z * nT;
   const int i0 = (bid % nIB) * BI, j0 = (bid / nIB) * BJ;
   const int HW = a.H * a.W;
   const int nchunks = (a.M + WPX - 1) / WPX;
