@@ -206,7 +206,11 @@ int nfk_step2d_fused_tiles(const nfk_step2d *s);
 void nfk_fused_set_stamps(void *buf);
 void nfk_fused_set_debug(int bits); /* diagnostic bisect of the fused kernel (results become wrong); 0 = off */
 int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zsave, void *h1save, void *h2save,
-                         float *hsave, float *zout, float *ldpart, void *stream);
+                         float *hsave, float *zout, float *ldpart, float *ws, void *stream);
+/* ws: nfk_step2d_fused_ws_floats(s) floats (0 for most steps).  Non-zero means the step runs "hidden split": grids that
+ * would fill only 16-64 CUs give every pixel tile to 4 workgroups, each with a quarter of conv2/conv3, partial sums in
+ * ws, finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows. */
+size_t nfk_step2d_fused_ws_floats(const nfk_step2d *s);
 int nfk_ld_finish(const float *ld_in, const float *ldpart, int nsteps, int B, int tiles, float *ld_out, void *stream);
 /* Split2d.forward / reverse / backward */
 int nfk_split2d_fwd(const nfk_split2d *s, const float *x, const float *ld_in, float *z1out, float *hsave,
@@ -269,8 +273,10 @@ enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW
        /* nfk_step2d_fwd_fused by conv3 width (one template instance each for Glow's shapes: CIFAR levels 1 / 2 / 3):
         * flops of the three convs, bytes = x + z + weights (+ what a training forward saves) */
        NFK_PROF_FUSED_STEP = 5, NFK_PROF_FUSED_STEP_NT2 = 6, NFK_PROF_FUSED_STEP_NT3 = 7,
-       NFK_PROF_DUAL_BWD = 8,   /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode) */
-       NFK_PROF_CLASSES = 9 };
+       /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode): 9 classes = conv (block.4, .2, .0) x size bucket
+        * (M >= 8192, >= 2048, smaller: CIFAR levels 1 / 2 / 3 at B = 64), one template instance each for Glow's shapes */
+       NFK_PROF_DUAL_BWD = 8,
+       NFK_PROF_CLASSES = 17 };
 void nfk_profile_begin(void);
 /* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
  * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(1024) coupling_fwd_kernel(CouplingArgs a) {
   }
   if (a.has_ld) {
     ls = block_sum(ls, sh);
-    if (threadIdx.x == 0) a.ld_out[b] = a.ld_in[b] + a.dld[0] + ls;
+    if (threadIdx.x == 0) a.ld_out[b] = (a.ld_in ? a.ld_in[b] : 0.f) + a.dld[0] + ls;
   }
 }
 

@@ -536,6 +536,7 @@ extern "C" {
 void nfk_fused_set_stamps(void* buf) { g_stamps = reinterpret_cast<unsigned long long*>(buf); }
 void nfk_fused_set_debug(int bits) {
   g_dbg = bits & 0xff; g_force_fused = (bits >> 8) & 1; g_no_v2 = (bits >> 9) & 1;
+  fused2_set_split(((bits >> 10) & 1) ? 0 : 1);   // bit 10: no hidden split
 }
 
 static int v2_tiles(const nfk_step2d& s) {
@@ -553,10 +554,12 @@ int nfk_step2d_fused_tiles(const nfk_step2d* s) {
 }
 
 static int step2d_fwd_fused_impl(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save,
-                                 void* h2save, float* hsave, float* zout, float* ldpart, void* stream);
+                                 void* h2save, float* hsave, float* zout, float* ldpart, float* ws, void* stream);
+
+size_t nfk_step2d_fused_ws_floats(const nfk_step2d* s) { return v2_tiles(*s) ? fused2_ws_floats(*s) : 0; }
 
 int nfk_step2d_fwd_fused(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save, void* h2save,
-                         float* hsave, float* zout, float* ldpart, void* stream) {
+                         float* hsave, float* zout, float* ldpart, float* ws, void* stream) {
   // algorithmic work of one FlowStep forward (bench.py roofline leg): the three convs' FLOPs; HBM bytes = the step's
   // input and output, its bf16 weights once, and what a training forward keeps for the backward
   const double M = (double)s->B * s->H * s->W, hid = s->hidden, K1 = 9.0 * (s->C / 2);
@@ -570,17 +573,17 @@ int nfk_step2d_fwd_fused(const nfk_step2d* s, const float* x, int ldx, float* zs
   int cls = NFK_PROF_FUSED_STEP + (s->Cout + 15) / 16 - 1;
   if (cls > NFK_PROF_FUSED_STEP_NT3) cls = NFK_PROF_FUSED_STEP_NT3;
   prof_scope_begin(cls, flops, bytes, st);
-  const int rc = step2d_fwd_fused_impl(s, x, ldx, zsave, h1save, h2save, hsave, zout, ldpart, stream);
+  const int rc = step2d_fwd_fused_impl(s, x, ldx, zsave, h1save, h2save, hsave, zout, ldpart, ws, stream);
   prof_scope_end(cls, st);
   return rc;
 }
 
 static int step2d_fwd_fused_impl(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save,
-                                 void* h2save, float* hsave, float* zout, float* ldpart, void* stream) {
+                                 void* h2save, float* hsave, float* zout, float* ldpart, float* ws, void* stream) {
   if (v2_tiles(*s)) {
     FusedCall c{};
     c.s = *s; c.x = x; c.ldx = ldx; c.zsave = zsave; c.h1save = h1save; c.h2save = h2save; c.hsave = hsave;
-    c.zout = zout; c.ldpart = ldpart; c.stamps = g_stamps; c.dbg = g_dbg;
+    c.zout = zout; c.ldpart = ldpart; c.ws = ws; c.stamps = g_stamps; c.dbg = g_dbg;
     return fused2_launch(c, reinterpret_cast<hipStream_t>(stream));
   }
   FusedArgs a{};

@@ -97,7 +97,11 @@ __device__ __forceinline__ int f2_h1_off(int px, int slot) {
 // h2 chunk image: 256-byte rows (128 channels = 16 slots), slot ^ (px & 15)
 __device__ __forceinline__ int f2_h2_off(int px, int slot) { return px * 256 + (((slot ^ px) & 15) << 4); }
 
-template <int MT32, int NT3, int K1M>
+// NS > 1 ("hidden split", for grids that would fill only 64 or 16 CUs): NS workgroups share a pixel tile; each runs
+// the whole mix / im2col / conv1 but only its 4/NS chunks of conv2 + conv3, and leaves its partial conv3 sums in slab
+// q of a.c.ws; coupling_fwd_kernel (S = NS slabs) then finishes the step.  The conv2 / conv3 weight stream, which is
+// what a lone workgroup spends its time on, is divided by NS.
+template <int MT32, int NT3, int K1M, int NS>
 __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   constexpr int HID = 512;
   constexpr int MT_O = 4;   // 64 output pixels = 4 tiles of 16 (conv3 uses 16x16x32)
@@ -116,8 +120,11 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 operand roles (conv3)
 
   const int tps = (TS == 1) ? H / R : 1;
-  const int b0 = (TS == 1) ? blockIdx.x / tps : blockIdx.x * TS;
-  const int tile = (TS == 1) ? blockIdx.x - b0 * tps : 0;
+  const int wg = (NS == 1) ? (int)blockIdx.x : (int)blockIdx.x / NS, qs = (NS == 1) ? 0 : (int)blockIdx.x % NS;
+  constexpr int NCH = 4 / NS;   // conv2 chunks (of 128 channels) per workgroup
+  const int nc0 = qs * NCH;
+  const int b0 = (TS == 1) ? wg / tps : wg * TS;
+  const int tile = (TS == 1) ? wg - b0 * tps : 0;
   const int row0 = tile * R;
   const int zh = 2 * halo;
   auto stamp = [&](int i) {
@@ -226,7 +233,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (o + r < C) Zm[pz * C + o + r] = acc[r];
-      if (ok && a.c.zsave && rz >= zh && rz < zh + R) {
+      if (ok && a.c.zsave && qs == 0 && rz >= zh && rz < zh + R) {
         float* zp = a.c.zsave + ((long)b * HW + y * W + xx) * C + o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (o + r < C) zp[r] = acc[r];
@@ -297,8 +304,8 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     for (int u = 0; u < 16; ++u) f[u] = f2_ldw(r2, voffL, soff + u * 1024);
   };
   // the first chunk's W2 rows travel while conv1 computes
-  load_w2(0, 0, w2a);
-  load_w2(0, 1, w2b);
+  load_w2(nc0, 0, w2a);
+  load_w2(nc0, 1, w2b);
   {
     const char* x1_lane = X1 + l32 * g.X1S + hi * 16;
     char* h1w[MT32];
@@ -359,7 +366,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     }
   }
   __syncthreads();
-  if (a.c.h1save) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, true);
+  if (a.c.h1save && qs == 0) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, true);
   stamp(3);
 
   // ------------------------------------------------------------------ 4./5. conv2 chunks feeding conv3
@@ -391,7 +398,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       w3[tap][nt] = f2_ldw(r3, voffL, (nt * (Kp3 / 32) + tap * 16 + nc * 4 + swid) * 1024);
   };
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) load_w3(0, tap);   // chunk 0; later chunks are reloaded in place by conv3
+  for (int tap = 0; tap < 9; ++tap) load_w3(nc0, tap);   // first chunk; later chunks are reloaded in place by conv3
   // h1 B-fragment address: px = mt*32 + l32 (px & 15 == l32 & 15), slot = 2*ks + hi:
   //   px*1024 + ((((2ks) & 15) ^ pc) | ((2ks) & 48)) * 16   with the lane constant pc = (l32 & 15) ^ hi
   // the XOR term takes 8 values per lane (k-step mod 8): 8 lane-constant addresses; m-tile and k-step/8 are immediates
@@ -456,15 +463,15 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  for (int nc = 0; nc < 4; ++nc) {
-    const int nn = min(nc + 1, 3);   // prefetches are unconditional (clamped): loads under a branch defeat vmcnt counting
+  for (int nc = nc0; nc < nc0 + NCH; ++nc) {
+    const int nn = min(nc + 1, nc0 + NCH - 1);   // prefetches are unconditional (clamped): loads under a branch defeat vmcnt counting
 #pragma unroll
     for (int mt = 0; mt < MT32; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
     conv2_half(0, w2a, nc, nn);
     conv2_half(1, w2b, nc, nn);
-    if (nc > 0) __syncthreads();
+    if (nc > nc0) __syncthreads();
     // every wave is done with the previous chunk image (conv3 and the h2 copy-out)
     const int nl = wid * 32 + 4 * hi;
 #pragma unroll
@@ -495,8 +502,23 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     for (int mo = 0; mo < MT_O; ++mo)
       *reinterpret_cast<f32x4*>(R3 + ((wid * 64 + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc3[nt][mo];
   __syncthreads();
-  __shared__ float sh2[32];
   const int per_px = R * W;
+  if (NS > 1) {
+    // partial conv3 sums of this workgroup's chunks -> slab qs; bias, scale and the coupling tail follow in
+    // coupling_fwd_kernel once all NS slabs are there
+    float* slab = a.c.ws + (long)qs * s.B * HW * Cout;
+    for (int idx = tid; idx < 64 * Cout; idx += 256) {
+      const int po = (int)__umulhi((unsigned)idx, 0xFFFFFFFFu / (unsigned)Cout + 1u), n = idx - po * Cout;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+      const int b = b0 + sm;
+      if (b >= s.B) continue;
+      const float* p = R3 + po * NP + n;
+      slab[((long)b * HW + (row0 + rr) * W + xx) * Cout + n] = (p[0] + p[64 * NP]) + (p[2 * 64 * NP] + p[3 * 64 * NP]);
+    }
+    stamp(5);
+    return;
+  }
+  __shared__ float sh2[32];
   const unsigned mC2 = 0xFFFFFFFFu / (unsigned)C2 + 1u, mCh = 0xFFFFFFFFu / (unsigned)Ch + 1u;
   for (int sm = 0; sm < TS; ++sm) {
     const int b = b0 + sm;
@@ -536,6 +558,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   stamp(5);
 }
 
+static int g_f2_split = 1;
 static int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
   int l = 0;
@@ -567,27 +590,33 @@ static bool f2_pick(const nfk_step2d& s, F2Args* a) {
   return true;
 }
 
-template <int MT32, int NT3, int K1M>
+template <int MT32, int NT3, int K1M, int NS>
 static int f2_launch_t(const F2Args& a, const F2Geom& g, int grid, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_step_fwd_kernel<MT32, NT3, K1M>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_step_fwd_kernel<MT32, NT3, K1M, NS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
       return NFK_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((fused2_step_fwd_kernel<MT32, NT3, K1M>), dim3(grid), dim3(256), g.total, st, a);
+  hipLaunchKernelGGL((fused2_step_fwd_kernel<MT32, NT3, K1M, NS>), dim3(grid * NS), dim3(256), g.total, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
 
-template <int MT32>
+template <int MT32, int NS>
 static int f2_dispatch(const F2Args& a, const F2Geom& g, int grid, hipStream_t st) {
   // instantiated for the shapes Glow produces: conv3 width grows with conv1's K (both follow C)
-  if (g.NT3 == 1 && g.K1M == 4) return f2_launch_t<MT32, 1, 4>(a, g, grid, st);
-  if (g.NT3 == 2 && g.K1M == 8) return f2_launch_t<MT32, 2, 8>(a, g, grid, st);
-  if (g.NT3 == 3 && g.K1M == 16) return f2_launch_t<MT32, 3, 16>(a, g, grid, st);
+  if (g.NT3 == 1 && g.K1M == 4) return f2_launch_t<MT32, 1, 4, NS>(a, g, grid, st);
+  if (g.NT3 == 2 && g.K1M == 8) return f2_launch_t<MT32, 2, 8, NS>(a, g, grid, st);
+  if (g.NT3 == 3 && g.K1M == 16) return f2_launch_t<MT32, 3, 16, NS>(a, g, grid, st);
   return NFK_ERR_ARG;
+}
+
+// hidden split for tiles that need no halo (whole images per workgroup) when the grid would leave most CUs idle
+static int f2_splits(const nfk_step2d& s, const F2Args& a, const F2Geom& g) {
+  const int grid = a.TS == 1 ? s.B * (s.H / a.R) : (s.B + a.TS - 1) / a.TS;
+  return (g_f2_split && g.MT32 == 2 && grid < 128) ? 4 : 1;
 }
 
 int fused2_tiles(const nfk_step2d& s) {
@@ -599,13 +628,33 @@ int fused2_tiles(const nfk_step2d& s) {
   return a.TS == 1 ? s.H / a.R : 1;
 }
 
+size_t fused2_ws_floats(const nfk_step2d& s) {
+  F2Args a{};
+  if (!f2_pick(s, &a)) return 0;
+  const F2Geom g = f2_geom(s, a.R, a.TS, a.halo);
+  const int ns = f2_splits(s, a, g);
+  return ns > 1 ? (size_t)ns * s.B * s.H * s.W * s.Cout : 0;
+}
+void fused2_set_split(int on) { g_f2_split = on; }
+
 int fused2_launch(const FusedCall& c, hipStream_t st) {
   F2Args a{};
   if (!f2_pick(c.s, &a)) return NFK_ERR_ARG;
   a.c = c;
   const F2Geom g = f2_geom(c.s, a.R, a.TS, a.halo);
   const int grid = a.TS == 1 ? c.s.B * (c.s.H / a.R) : (c.s.B + a.TS - 1) / a.TS;
-  return g.MT32 == 2 ? f2_dispatch<2>(a, g, grid, st) : f2_dispatch<3>(a, g, grid, st);
+  if (f2_splits(c.s, a, g) == 1)
+    return g.MT32 == 2 ? f2_dispatch<2, 1>(a, g, grid, st) : f2_dispatch<3, 1>(a, g, grid, st);
+  // hidden split: the step's mixed z must be kept (the coupling tail reads it), and the tail is a second launch
+  if (!c.ws || !c.zsave) return NFK_ERR_ARG;
+  { const int rc = f2_dispatch<2, 4>(a, g, grid, st); if (rc != NFK_OK) return rc; }
+  const nfk_step2d& s = c.s;
+  CouplingArgs cp{};
+  cp.a3 = c.ws; cp.S = 4; cp.slab_stride = (long)s.B * s.H * s.W * s.Cout;
+  cp.bias3 = s.bias3; cp.es3 = s.es3; cp.z = c.zsave; cp.ldz = s.C; cp.zout = c.zout; cp.ldo = s.C; cp.hsave = c.hsave;
+  cp.ld_in = nullptr; cp.dld = s.dld; cp.ld_out = c.ldpart;   // one log-det slot per sample (tiles == 1 here)
+  cp.HW = s.H * s.W; cp.C = s.C; cp.Cout = s.Cout; cp.additive = s.additive; cp.has_ld = 1;
+  return launch_coupling_fwd(cp, s.B, st);
 }
 
 }  // namespace nfk

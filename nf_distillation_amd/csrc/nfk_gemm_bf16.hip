@@ -17,6 +17,7 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int BKH = 64;                 // bf16 elements per k-chunk
+static int g_wgrad_wide_max_splits = 64;
 static int g_wgrad_target_wgs = 768, g_wgrad_max_splits = 64;   // nfk_set_tuning(200 + cap) / (1000 + target)
 static int g_big_tile_min_k = 256;      // see big_tiles(); nfk_set_tuning(100 + v) sets it to v*64 (experiments)
 constexpr unsigned OOB = 0x80000000u;
@@ -646,13 +647,14 @@ static int launch_dual(const ConvGemmArgs& d, int SD, const WgradArgs& w, int SW
     attr = true;
   }
   const int nbD = ceil_div(d.N, BN) * ceil_div(d.M, BM), nbW = ceil_div(w.NI, BI) * ceil_div(w.J, BJ);
-  prof_scope_begin(NFK_PROF_DUAL_BWD, 2.0 * d.M * (double)d.N * d.K + 2.0 * w.M * (double)w.NI * w.J,
+  const int cls = NFK_PROF_DUAL_BWD + 3 * ((d.N > 96) ? ((w.NI > 96) ? 1 : 0) : 2) + (d.M >= 8192 ? 0 : (d.M >= 2048 ? 1 : 2));
+  prof_scope_begin(cls, 2.0 * d.M * (double)d.N * d.K + 2.0 * w.M * (double)w.NI * w.J,
                    (d.xf32 ? 4.0 : 2.0) * d.M * d.Cin + 2.0 * d.N * d.K + (d.obf16 ? 2.0 : 4.0 * SD) * d.M * d.N +
                        (w.pbf16 ? 2.0 : 4.0) * w.M * w.NI + (w.qbf16 ? 2.0 : 4.0) * w.M * w.Cq + 4.0 * SW * w.NI * w.J,
                    st);
   hipLaunchKernelGGL((dual_dgrad_wgrad_bf16_kernel<CTN, CTM, CWN, CWM, XF32, GTN, GTM, GWN, GWM>),
                      dim3(nbD * SD + nbW * SW), dim3(256), lds, st, d, nbD, SD, w, nbW, SW);
-  prof_scope_end(NFK_PROF_DUAL_BWD, st);
+  prof_scope_end(cls, st);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
@@ -683,6 +685,7 @@ int wgrad_splits_bf16(int M, int NI, int J) {
   if (S > nchunks / 2) S = nchunks / 2;
   if (S < 1) S = 1;
   if (S > g_wgrad_max_splits) S = g_wgrad_max_splits;
+  if (NI > 96 && J > 96 && S > g_wgrad_wide_max_splits) S = g_wgrad_wide_max_splits;   // 1 MiB per split for 512x512
   return S;
 }
 
@@ -744,7 +747,8 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
 }
 
 void set_tuning_bf16(int v) {
-  if (v >= 900) g_wgrad_target_wgs = v - 900;
+  if (v >= 2000) g_wgrad_wide_max_splits = v - 2000;
+  else if (v >= 900) g_wgrad_target_wgs = v - 900;
   else if (v >= 100) g_wgrad_max_splits = v - 100;
   else g_big_tile_min_k = v * 64;
 }

@@ -117,11 +117,14 @@ struct FusedCall {
   float* hsave;          // [M][Cout] or null
   float* zout;           // [M][C]
   float* ldpart;         // [B][tiles per sample] partial log-det of this step
+  float* ws;             // fused2_ws_floats(s) floats: partial conv3 slabs of a hidden-split step (else unused)
   unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
   int dbg;                     // diagnostic bisect bits (0 in production)
 };
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 int fused2_launch(const FusedCall& c, hipStream_t st);
+size_t fused2_ws_floats(const nfk_step2d& s);
+void fused2_set_split(int on);
 
 void set_tuning(int v);
 void prof_begin();

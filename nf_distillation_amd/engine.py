@@ -456,9 +456,16 @@ class _EncodeFn(torch.autograd.Function):
                     saved.append((cur, zb, h1, h2, hs, arena))
                 else:
                     saved.append(None)
+                nws = lib.nfk_step2d_fused_ws_floats(C.byref(r.cs))
+                ws = None
+                if nws:   # hidden-split step: partial conv3 slabs + (always) the mixed z for the coupling launch
+                    if zb is None:
+                        zb, ws = scratch.get(M_ * r.C, nws)
+                    else:
+                        (ws,) = scratch.get(nws)
                 part = run["buf"].data_ptr() + 4 * run["k"] * B * tiles
                 check(lib.nfk_step2d_fwd_fused(C.byref(r.cs), ptr(cur), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs), ptr(out),
-                                               part, s), "nfk_step2d_fwd_fused")
+                                               part, ptr(ws), s), "nfk_step2d_fwd_fused")
                 run["k"] += 1
                 if run["k"] == run["n"]:
                     ld_out = torch.empty_like(ld)

@@ -81,13 +81,13 @@ def test_distillation_step_trains():
     assert float(out["result_loss"]) < first
 
 
-@pytest.mark.parametrize("dbg", [0, 0x100, 0x300], ids=["policy", "forced_every_level", "gen1_forced"])
+@pytest.mark.parametrize("dbg", [0, 0x400, 0x300], ids=["policy", "no_hidden_split", "gen1_forced"])
 @pytest.mark.parametrize("name", ["cifar_k8_full", "glow32"])
 def test_fused_step_equals_unfused(name, dbg):
     """The one-launch FlowStep forward (csrc/nfk_fused2.hip; generation 1 in nfk_fused.hip) against the five-kernel
     bf16 path: same bf16 roundings of h1/h2/weights, so outputs agree to fp32 summation-order noise; gradients (same
-    backward) likewise.  `dbg` bit 8 forces the fused step where the policy would not pick it (levels 2 and 3), bit 9
-    selects generation 1."""
+    backward) likewise.  `dbg` bit 8 forces generation 1 where its policy would not pick it (levels 2 and 3), bit 9 selects
+    generation 1, bit 10 switches off the hidden split generation 2 uses on small grids."""
     from nf_distillation_amd import capi
     capi.lib().nfk_fused_set_debug(dbg)
     try:
