@@ -239,6 +239,14 @@ int nfk_tab_bwd(const nfk_tab_step *s, const nfk_tab_grads *g, const float *x, c
 /* sumsq[0] += sum g^2 over n elements (deterministic two-stage tree); partial: >= 1024 floats */
 int nfk_sumsq(const float *g, size_t n, float *partial, float *sumsq, void *stream);
 
+/* Image pipeline on the device (data/src/utils.py:7-25 behind torchvision's ToTensor; data/src/cifar10.py:17-20):
+ * preprocess: uint8 [B][H][W][C] -> fp32 [B][C][H][W], x = ((u/255)*255)/256 - 0.5 in the reference's own order of fp32
+ * operations (bit-identical), flip[b] != 0 mirrors sample b horizontally (may be NULL);
+ * postprocess: fp32 NCHW -> uint8 HWC, clamp(x,-0.5,0.5)+0.5, *255, clamp [0,255], truncation. */
+int nfk_preprocess_u8(const unsigned char *u8_hwc, const unsigned char *flip, float *out_nchw, int B, int H, int W, int C,
+                      void *stream);
+int nfk_postprocess_u8(const float *x_nchw, unsigned char *u8_hwc, int B, int H, int W, int C, void *stream);
+
 /* Distillation loss of the hint-MSE + NLL branch of NFModel.loss (pl_module.py:246-300):
  *   kd[b] = 1/P * sum_p mean_i (s_p[b][i] - t_p[b][i])^2,   result = mean_b (w_nll * nll[b] + w_kd * kd[b]).
  * s_p / t_p: P pairs of dense per-sample-contiguous tensors with per_sample[p] elements per sample (same memory order

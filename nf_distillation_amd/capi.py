@@ -140,6 +140,8 @@ _PROTOS = {
     "nfk_tab_inv": (i32, [C.POINTER(TabStepC), vp, vp, vp, vp, vp, vp]),
     "nfk_tab_bwd": (i32, [C.POINTER(TabStepC), C.POINTER(TabGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_sumsq": (i32, [vp, u64, vp, vp, vp]),
+    "nfk_preprocess_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "nfk_postprocess_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nfk_kd_loss_fwd": (i32, [C.POINTER(KdPairs), vp, f32, f32, vp, vp, vp, vp]),
     "nfk_kd_loss_bwd": (i32, [C.POINTER(KdPairs), vp, f32, f32, C.POINTER(KdGrads), vp]),
     "nfk_adam_step": (i32, [vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),

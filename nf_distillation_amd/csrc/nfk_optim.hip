@@ -117,6 +117,46 @@ __global__ void __launch_bounds__(256) kd_bwd_kernel(nfk_kd_pairs a, const float
   for (long i = threadIdx.x; i < n; i += 256) o[i] = coef * (s[i] - t[i]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Input / output image pipeline on the device (data/src/utils.py:7-25 after torchvision's ToTensor):
+//   preprocess : uint8 HWC -> fp32 NCHW, x = ((u / 255) * 255) / 256 - 0.5 (the reference's own sequence of fp32
+//                operations, so the result is bit-identical), optional per-sample horizontal flip
+//                (transforms.RandomHorizontalFlip, data/src/cifar10.py:17-20)
+//   postprocess: fp32 NCHW -> uint8 HWC, clamp(x, -0.5, 0.5) + 0.5, * 255, clamp to [0, 255], truncate
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_u8_kernel(const unsigned char* __restrict__ u,
+                                                            const unsigned char* __restrict__ flip,
+                                                            float* __restrict__ out, int B, int H, int W, int C) {
+  const long total = (long)B * C * H * W;
+  for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int x = t % W;
+    long r = t / W;
+    const int y = r % H; r /= H;
+    const int c = r % C;
+    const int b = r / C;
+    const int xs = (flip && flip[b]) ? W - 1 - x : x;
+    float v = (float)u[(((long)b * H + y) * W + xs) * C + c];
+    v = v / 255.f;
+    v = v * 255.f;
+    out[t] = v / 256.f - 0.5f;
+  }
+}
+__global__ void __launch_bounds__(256) postprocess_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ u,
+                                                             int B, int H, int W, int C) {
+  const long total = (long)B * C * H * W;
+  for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int c = t % C;
+    long r = t / C;
+    const int xx = r % W; r /= W;
+    const int y = r % H;
+    const int b = r / H;
+    float v = x[(((long)b * C + c) * H + y) * W + xx];
+    v = fminf(fmaxf(v, -0.5f), 0.5f) + 0.5f;
+    v = fminf(fmaxf(v * 255.f, 0.f), 255.f);
+    u[t] = (unsigned char)v;
+  }
+}
+
 extern "C" {
 int nfk_sumsq(const float* g, size_t n, float* partial, float* sumsq, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -174,6 +214,27 @@ int nfk_kd_loss_bwd(const nfk_kd_pairs* pairs, const float* g_result, float w_nl
   if (pairs->B <= 0 || pairs->n <= 0 || pairs->n > NFK_KD_MAX_PAIRS) return NFK_ERR_ARG;
   hipLaunchKernelGGL(kd_bwd_kernel, dim3(pairs->B, pairs->n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      *pairs, g_result, w_nll, w_kd, *grads);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_preprocess_u8(const unsigned char* u8_hwc, const unsigned char* flip, float* out_nchw, int B, int H, int W, int C,
+                      void* stream) {
+  const long total = (long)B * C * H * W;
+  if (total <= 0) return NFK_OK;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), u8_hwc,
+                     flip, out_nchw, B, H, W, C);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_postprocess_u8(const float* x_nchw, unsigned char* u8_hwc, int B, int H, int W, int C, void* stream) {
+  const long total = (long)B * C * H * W;
+  if (total <= 0) return NFK_OK;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(postprocess_u8_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x_nchw,
+                     u8_hwc, B, H, W, C);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
