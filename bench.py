@@ -222,10 +222,22 @@ def main():
             achieved, peak, unit = nbytes / avg_s / 1e9, HBM_PEAK_GBPS, "GB/s"
         else:
             achieved, peak, unit = flops / avg_s / 1e12, mfma_peak, "TFLOP/s"
+        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE with the gfx950
+        # fetch correction, tools/pmc_traffic.py) -- bench.py cannot collect counters itself; null if the profile does
+        # not hold this kernel
+        traffic, traffic_src = None, None
+        sym = {"<*,1,*>": "nfk::fused2_step_fwd_kernel<3, 1, 4>", "<*,2,*>": "nfk::fused2_step_fwd_kernel<2, 2, 8>",
+               "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16>"}
+        pmc_file = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_bf16.json")
+        if args.dtype == "bf16" and os.path.exists(pmc_file):
+            kern = json.load(open(pmc_file)).get("kernels", {})
+            for tag, name in sym.items():
+                if tag in dom["kernel"] and name in kern:
+                    traffic, traffic_src = kern[name]["hbm_bytes_per_launch_corrected"], "profiles/r01_d_pmc_traffic_bf16.json"
         result["roofline"] = {
             "bound": "hbm" if hbm_bound else "mfma",
             "kernel": dom["kernel"] + (" [bf16 operands]" if args.dtype == "bf16" else " [f32]"),
-            "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": None,
+            "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": dom["launches"] / args.steps, "avg_launch_us": 1e6 * avg_s,
             "algorithmic_gflop_per_launch": flops / 1e9, "algorithmic_mbytes_per_launch": nbytes / 1e6,
             "achieved_tflops": flops / avg_s / 1e12,
