@@ -128,6 +128,12 @@ size_t nfk_split2d_bwd_ws_floats(const nfk_split2d *s);
 int nfk_prep(const nfk_prep_desc *descs, int nsteps, int want_inverse, void *stream);
 int nfk_prep_bwd(const nfk_prep_desc *descs, const nfk_prep_grad *grads, int nsteps, const float *g_logdet,
                  int B, int any_dense, void *stream);
+/* Backward of the INVERSE products of nfk_prep (Wi, ci), for a reverse pass that carries gradients (1-D perceptual
+ * branch, pl_module.py:229-243): grads[i].part = [nparts][C*C + C] partial (g_Wi, g_ci) of step i (nparts == 0: step
+ * skipped); g_logdet = dL/d(logdet of the reverse pass) or NULL.  Accumulates into the same parameter gradients as
+ * nfk_prep_bwd.  C <= 74. */
+int nfk_prep_inv_bwd(const nfk_prep_desc *descs, const nfk_prep_grad *grads, int nsteps, const float *g_logdet,
+                     int B, void *stream);
 /* conv.weight [Cout][Cin][taps] -> wt [Cout][Kp(taps*Cin)] and (optional) wd [Cin][Kp(taps*Cout)]
  * (flipped taps).  Replaces nn.ZeroPad2d + nn.Conv2d weight handling (models/layers.py:208-211). */
 int nfk_repack(const float *w, int Cout, int Cin, int taps, float *wt, float *wd, void *stream);
@@ -234,6 +240,13 @@ int nfk_tab_inv(const nfk_tab_step *s, const float *y, const float *cond, const 
 int nfk_tab_bwd(const nfk_tab_step *s, const nfk_tab_grads *g, const float *x, const float *cond,
                 const float *g_out, const float *g_ld, float *g_x, float *g_cond, float *part, float *part_mix,
                 void *stream);
+
+/* backward of nfk_tab_inv (reverse pass with gradients): g_x = dL/dx of the reverse OUTPUT -> g_y (its input), g_cond,
+ * MLP parameter gradients (via part, as nfk_tab_bwd) and part_mix = partial (g_Wi, g_ci) for nfk_prep_inv_bwd.
+ * g_ld = dL/d(ld_out) or NULL. */
+int nfk_tab_inv_bwd(const nfk_tab_step *s, const nfk_tab_grads *g, const float *y, const float *cond,
+                    const float *g_x, const float *g_ld, float *g_y, float *g_cond, float *part, float *part_mix,
+                    void *stream);
 
 /* ---- optimiser (torch.optim.Adam + clip_grad_norm_, pl_module.py:350-354, train.py:46) ------ */
 /* sumsq[0] += sum g^2 over n elements (deterministic two-stage tree); partial: >= 1024 floats */

@@ -102,6 +102,7 @@ _PROTOS = {
     "nfk_split2d_bwd_ws_floats": (u64, [C.POINTER(Split2d)]),
     "nfk_prep": (i32, [vp, i32, i32, vp]),
     "nfk_prep_bwd": (i32, [vp, vp, i32, vp, i32, i32, vp]),
+    "nfk_prep_inv_bwd": (i32, [vp, vp, i32, vp, i32, vp]),
     "nfk_repack": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "nfk_repack_batch": (i32, [vp, i32, vp]),
     "nfk_repack_batch_bf16": (i32, [vp, i32, vp]),
@@ -139,6 +140,7 @@ _PROTOS = {
     "nfk_tab_fwd": (i32, [C.POINTER(TabStepC), vp, vp, vp, vp, vp, vp]),
     "nfk_tab_inv": (i32, [C.POINTER(TabStepC), vp, vp, vp, vp, vp, vp]),
     "nfk_tab_bwd": (i32, [C.POINTER(TabStepC), C.POINTER(TabGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_tab_inv_bwd": (i32, [C.POINTER(TabStepC), C.POINTER(TabGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_sumsq": (i32, [vp, u64, vp, vp, vp]),
     "nfk_preprocess_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "nfk_postprocess_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),

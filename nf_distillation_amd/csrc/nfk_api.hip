@@ -121,6 +121,10 @@ int nfk_prep_bwd(const nfk_prep_desc* descs, const nfk_prep_grad* grads, int nst
                  int any_dense, void* stream) {
   return launch_prep_bwd(descs, grads, nsteps, g_logdet, B, any_dense, S_(stream));
 }
+int nfk_prep_inv_bwd(const nfk_prep_desc* descs, const nfk_prep_grad* grads, int nsteps, const float* g_logdet, int B,
+                     void* stream) {
+  return launch_prep_inv_bwd(descs, grads, nsteps, g_logdet, B, S_(stream));
+}
 int nfk_repack(const float* w, int Cout, int Cin, int taps, float* wt, float* wd, void* stream) {
   if (taps != 1 && taps != 9) return NFK_ERR_ARG;
   return repack_weights(w, Cout, Cin, taps, wt, wd, S_(stream));

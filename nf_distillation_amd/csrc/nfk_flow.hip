@@ -20,6 +20,7 @@ namespace nfk {
 // ==========================================================================================
 // small dense helpers on global scratch, executed by ONE workgroup
 // ==========================================================================================
+constexpr size_t PREP_INV_BWD_LDS = 152 * 1024;   // seven C x C matrices: C <= 74
 constexpr size_t PREP_LDS = 60 * 1024, PREP_BWD_LDS = 60 * 1024;   // dynamic LDS of prep_kernel / prep_bwd_kernel
 // C[n][n] = A * B   (opA/opB: 0 = as is, 1 = transposed)
 __device__ void blk_matmul(const float* A, int ta, const float* B, int tb, float* C, int n) {
@@ -184,6 +185,30 @@ __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __rest
 }
 
 
+// W = P L U: chain a gradient GW (indexed like W) to (lower, upper, log_s); Gs is added to every g_log_s (the log-det
+// term).  T0, T1, T2, Wk: C*C scratch matrices (T0 / T1 are overwritten with L / U).  Block-wide; accumulates.
+__device__ void prep_lu_chain(const PrepDesc& d, const PrepGrad& g, int C, const float* P, const float* GW, float* Wk,
+                              float* T0, float* T1, float* T2, float Gs) {
+  const int CC = C * C;
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+    const int i = idx / C, j = idx % C;
+    T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
+    T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
+  }
+  __syncthreads();
+  blk_matmul(P, 1, GW, 0, T2, C);     // T2 = P^T gW
+  blk_matmul(T2, 0, T1, 1, Wk, C);    // Wk = P^T gW U^T   -> g_L
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x)
+    if (idx / C > idx % C) g.g_lower[idx] += Wk[idx];
+  __syncthreads();
+  blk_matmul(T0, 1, T2, 0, Wk, C);    // Wk = L^T P^T gW    -> g_U
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+    const int i = idx / C, j = idx % C;
+    if (i < j) g.g_upper[idx] += Wk[idx];
+    else if (i == j) g.g_log_s[i] += Wk[idx] * d.sign_s[i] * expf(d.log_s[i]) + Gs;
+  }
+}
+
 // Backward of prep: chain (gWf, gcf, G = sum_b g_logdet[b]) to the raw parameters; accumulates.
 //   part: [nparts][C*C + C] partial sums of  gWf[o][c] = sum_m gz[m][o] x[m][c],  gcf[o] = sum_m gz[m][o]
 __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
@@ -241,26 +266,7 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
     if (d.is_1d) GW[c * C + o] = v; else GW[idx] = v;
   }
   __syncthreads();
-  if (d.perm_kind == PERM_LU) {
-    // L -> T0, U -> T1
-    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
-      const int i = idx / C, j = idx % C;
-      T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
-      T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
-    }
-    __syncthreads();
-    blk_matmul(P, 1, GW, 0, T2, C);     // T2 = P^T gW
-    blk_matmul(T2, 0, T1, 1, W, C);     // W  = P^T gW U^T   -> g_L
-    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x)
-      if (idx / C > idx % C) g.g_lower[idx] += W[idx];
-    __syncthreads();
-    blk_matmul(T0, 1, T2, 0, W, C);     // W = L^T P^T gW     -> g_U
-    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
-      const int i = idx / C, j = idx % C;
-      if (i < j) g.g_upper[idx] += W[idx];
-      else if (i == j) g.g_log_s[i] += W[idx] * d.sign_s[i] * expf(d.log_s[i]) + G;
-    }
-  }
+  if (d.perm_kind == PERM_LU) prep_lu_chain(d, g, C, P, GW, W, T0, T1, T2, G);
 }
 
 // Dense-weight variant needs GW after the inverse; done in a second tiny kernel to keep scratch small.
@@ -294,6 +300,73 @@ __global__ void __launch_bounds__(256) prep_bwd_dense_kernel(const PrepDesc* __r
     // d log|det W| / dW = W^-T
     if (d.is_1d) g.g_weight[c * C + o] += v + G * T0[o * C + c];
     else g.g_weight[idx] += v + G * T0[c * C + o];
+  }
+}
+
+// Backward of prep's INVERSE products (nfk_prep with want_inverse: Wi, ci used by the reverse pass), for reverse passes
+// that carry gradients.  part (slab 0 after part_reduce_kernel) holds g_Wi [C][C] and g_ci [C]; gld = dL/d(logdet) of the
+// reverse pass, whose logdet is logdet_in - dld (so every log-det parameter gets -G).
+//   ci = -bias                                   -> g_bias -= g_ci
+//   Wi[c][o] = Y(c,o) e^{-logs[c]},  Y(c,o) = Winv[o][c] (1-D) or Winv[c][o] (2-D)
+//                                                -> g_logs[c] -= sum_o g_Wi[c][o] Wi[c][o] + G ;  g_Y = g_Wi e^{-logs[c]}
+//   Winv = W^-1                                  -> g_W = -Winv^T g_Winv Winv^T, then the P L U chain (or g_weight)
+__global__ void __launch_bounds__(256) prep_inv_bwd_kernel(const PrepDesc* __restrict__ descs,
+                                                           const PrepGrad* __restrict__ grads,
+                                                           const float* __restrict__ gld, int B) {
+  __shared__ float sh[32];
+  PrepDesc d = descs[blockIdx.x];
+  const PrepGrad g = grads[blockIdx.x];
+  const int C = d.C, CC = C * C;
+  if (C == 0 || g.nparts <= 0) return;
+  extern __shared__ __attribute__((aligned(16))) float pi_lds[];
+  const bool in_lds = (size_t)7 * CC * sizeof(float) <= PREP_INV_BWD_LDS;   // C <= 74 (checked by the caller)
+  float* W = in_lds ? pi_lds : d.scratch;   // the global scratch holds 5 matrices: 6 and 7 only exist in LDS
+  float* T0 = W + CC;
+  float* T1 = T0 + CC;
+  float* AUG = T1 + CC;                      // 2 CC
+  float* GY = in_lds ? AUG + 2 * CC : nullptr;
+  float* T2 = in_lds ? GY + CC : nullptr;
+  if (!in_lds) return;
+  float G = 0.f;
+  if (gld) for (int b = threadIdx.x; b < B; b += blockDim.x) G += gld[b];
+  G = block_sum(G, sh) * (float)d.pixels;
+  build_W(d, W, T0, T1, sh);                 // W (uses T0/T1 as scratch)
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) T2[idx] = W[idx];
+  __syncthreads();
+  blk_inverse(T2, T0, AUG, C, sh);           // T0 = W^-1
+  // g_bias, g_logs, g_Winv (indexed like Winv) -> GY
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    g.g_an_bias[c] -= g.part[CC + c];
+    const float e = expf(-d.an_logs[c]);
+    float t = 0.f;
+    for (int o = 0; o < C; ++o) {
+      const float y = d.is_1d ? T0[o * C + c] : T0[c * C + o];
+      t += g.part[c * C + o] * y * e;
+    }
+    g.g_an_logs[c] += -t - G;
+  }
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+    const int c = idx / C, o = idx - c * C;
+    const float v = g.part[idx] * expf(-d.an_logs[c]);
+    if (d.is_1d) GY[o * C + c] = v; else GY[idx] = v;
+  }
+  __syncthreads();
+  blk_matmul(T0, 1, GY, 0, T1, C);           // T1 = Winv^T gWinv
+  blk_matmul(T1, 0, T0, 1, AUG, C);          // AUG = Winv^T gWinv Winv^T
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) AUG[idx] = -AUG[idx];   // g_W
+  __syncthreads();
+  if (d.perm_kind == PERM_LU) {
+    float* Pl = AUG + CC;                    // second half of AUG
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];
+    __syncthreads();
+    prep_lu_chain(d, g, C, Pl, AUG, W, T0, T1, T2, -G);
+  } else if (d.perm_kind == PERM_DENSE) {
+    // d(-log|det W|)/dW = -W^-T ; T0 still holds W^-1
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+      const int i = idx / C, j = idx - i * C;
+      g.g_weight[idx] += AUG[idx] - G * T0[j * C + i];
+    }
   }
 }
 
@@ -802,6 +875,23 @@ int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int ns
     hipLaunchKernelGGL(prep_bwd_dense_kernel, dim3(nsteps), dim3(256), 0, st, descs_dev, grads_dev, gld, B);
     NFK_LAUNCH_CHECK();
   }
+  return NFK_OK;
+}
+
+int launch_prep_inv_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
+                        hipStream_t st) {
+  if (nsteps <= 0) return NFK_OK;
+  hipLaunchKernelGGL(part_reduce_kernel, dim3(145, nsteps), dim3(256), 0, st, descs_dev, grads_dev);
+  NFK_LAUNCH_CHECK();
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(prep_inv_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_INV_BWD_LDS) != hipSuccess)
+      return NFK_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(prep_inv_bwd_kernel, dim3(nsteps), dim3(256), PREP_INV_BWD_LDS, st, descs_dev, grads_dev, gld, B);
+  NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
 

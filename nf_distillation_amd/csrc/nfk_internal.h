@@ -153,6 +153,8 @@ int wgrad_finalize(const float* slabs, int S, long slab_stride, int Cout, int Ci
 int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st);
 int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
                     int any_dense, hipStream_t st);
+int launch_prep_inv_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
+                        hipStream_t st);
 int launch_chanmix(const ChanMixArgs& a, hipStream_t st);
 int chanmix_parts(int M, int C);
 int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st);

@@ -253,6 +253,34 @@ __device__ void tab_wgrad(const float* g, int ldg, const float* in, int ldi, int
   }
 }
 
+// MLP backward (layers 5..0) for the tile whose forward activations (IN0, H[0..4]) are in LDS and whose gradient wrt the
+// last layer's output is in L.GA.  Accumulates the weight-gradient partial sums into L.Pl; returns the gradient wrt the
+// first layer's input IN0 = (z1 | cond) (in L.GA or L.GB).  Block-wide.
+__device__ const float* tab_mlp_backward(const TabStep& s, const TabLds& L) {
+  const int TR = L.TR;
+  float* g = L.GA;
+  float* gn = L.GB;
+  for (int l = 5; l >= 0; --l) {
+    const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
+    const float* in = l == 0 ? L.IN0 : L.H[l - 1];
+    const int ldi = l == 0 ? L.IS : L.HS;
+    tab_wgrad(g, L.GS, in, ldi, nin, no, L.Pl + tab_param_off(s, l), TR);
+    // grad wrt this layer's input (post-activation of layer l-1)
+    tab_dense(g, L.GS, no, s.W[l], nullptr, gn, L.GS, nin, 0, 1, L.Wl, TR);
+    if (l > 0) {
+      const int act = (l - 1) == 4 ? 2 : 1;
+      for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
+        const int p = idx / nin, c = idx - p * nin;
+        const float h = L.H[l - 1][p * L.HS + c];
+        gn[p * L.GS + c] *= act == 1 ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
+      }
+      __syncthreads();
+    }
+    float* t = g; g = gn; gn = t;
+  }
+  return g;
+}
+
 __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __restrict__ x,
                                                       const float* __restrict__ cond, const float* __restrict__ gout,
                                                       const float* __restrict__ gld, float* __restrict__ gx,
@@ -287,27 +315,7 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
       }
     }
     __syncthreads();
-    // ---- MLP backward (layers 5..0).  g = grad wrt the layer's PRE-activation output.
-    float* g = L.GA;
-    float* gn = L.GB;
-    for (int l = 5; l >= 0; --l) {
-      const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
-      const float* in = l == 0 ? L.IN0 : L.H[l - 1];
-      const int ldi = l == 0 ? L.IS : L.HS;
-      tab_wgrad(g, L.GS, in, ldi, nin, no, L.Pl + tab_param_off(s, l), TR);
-      // grad wrt this layer's input (post-activation of layer l-1)
-      tab_dense(g, L.GS, no, s.W[l], nullptr, gn, L.GS, nin, 0, 1, L.Wl, TR);
-      if (l > 0) {
-        const int act = (l - 1) == 4 ? 2 : 1;
-        for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
-          const int p = idx / nin, c = idx - p * nin;
-          const float h = L.H[l - 1][p * L.HS + c];
-          gn[p * L.GS + c] *= act == 1 ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
-        }
-        __syncthreads();
-      }
-      float* t = g; g = gn; gn = t;
-    }
+    const float* g = tab_mlp_backward(s, L);
     // g = grad wrt IN0 = (z1 | cond)
     for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
       const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
@@ -327,12 +335,116 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
       }
       L.PM[idx] += sacc;
     }
+    float* gn = (g == L.GA) ? L.GB : L.GA;   // the buffer the MLP backward is done with
     tab_dense(L.GY, L.XS, d, s.Wf, nullptr, gn, L.GS, d, 0, 1, L.Wl, TR);
     for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
       const int p = idx / d, c = idx - p * d, m = row0 + p;
       if (m < s.B) gx[(long)m * d + c] = gn[p * L.GS + c];
     }
     __syncthreads();
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) part[(long)blockIdx.x * NP + i] = L.Pl[i];
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) part_mix[(long)blockIdx.x * NM + i] = L.PM[i];
+}
+
+// Backward of tab_inv_kernel (the reverse / sampling pass with gradients: the perceptual branch of the tabular
+// distillation loss, pl_module.py:229-243).  Given g_x = dL/dx of the step's reverse OUTPUT x = Wi z + ci:
+//   g_z = Wi^T g_x, partial (g_Wi, g_ci)            -> part_mix (same [d*d + d] layout as the forward's (gWf, gcf))
+//   z2 = y2 / s - shift, s = sigmoid(sr + 2)        -> g_y2 = g_z2 / s, g_shift = -g_z2, g_sr = -g_z2 y2 (1 - s) / s
+//   additive: z2 = y2 - h                           -> g_y2 = g_z2, g_h = -g_z2
+//   logdet_out = logdet_in - dld - sum log s        -> g_sr -= g_ld (1 - s)
+//   MLP backward                                    -> part, g_z1 += ..., g_cond
+// The tile's reverse forward is recomputed in LDS first (y -> MLP -> z).
+__global__ void __launch_bounds__(256) tab_inv_bwd_kernel(TabStep s, const float* __restrict__ y,
+                                                          const float* __restrict__ cond, const float* __restrict__ gxo,
+                                                          const float* __restrict__ gld, float* __restrict__ gy,
+                                                          float* __restrict__ gcond, float* __restrict__ part,
+                                                          float* __restrict__ part_mix) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TabLds L;
+  tab_layout(s, true, &L, smem);
+  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s);
+  const int NP = tab_param_floats(s), NM = d * d + d;
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) L.PM[i] = 0.f;
+  const int ntiles = (s.B + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TR;
+    __syncthreads();
+    // ---- recompute: Y = y tile, IN0 = (z1 | cond), MLP, X = z = (z1 | z2); GY = g_x tile
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      L.Y[p * L.XS + c] = m < s.B ? y[(long)m * d + c] : 0.f;
+      L.GY[p * L.XS + c] = m < s.B ? gxo[(long)m * d + c] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+      const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+      L.IN0[p * L.IS + c] = c < Ch ? L.Y[p * L.XS + c] : (m < s.B ? cond[(long)m * s.ncond + (c - Ch)] : 0.f);
+    }
+    const float* in = L.IN0;
+    int ldi = L.IS;
+    for (int l = 0; l < 5; ++l) {
+      tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+      in = L.H[l];
+      ldi = L.HS;
+    }
+    tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d;
+      float v = L.Y[p * L.XS + c];
+      if (c >= Ch) {
+        const int j = c - Ch;
+        if (s.additive) v -= L.O[p * L.OS + j];
+        else v = v * (1.f + expf(-(L.O[p * L.OS + 2 * j + 1] + 2.f))) - L.O[p * L.OS + 2 * j];
+      }
+      L.X[p * L.XS + c] = v;
+    }
+    __syncthreads();
+    // ---- final mix backward: partial (g_Wi, g_ci), g_z = Wi^T g_x -> GB
+    for (int idx = threadIdx.x; idx < NM; idx += blockDim.x) {
+      float sacc = 0.f;
+      if (idx < d * d) {
+        const int o = idx / d, c = idx - o * d;
+        for (int p = 0; p < TR; ++p) sacc += L.GY[p * L.XS + o] * L.X[p * L.XS + c];
+      } else {
+        const int o = idx - d * d;
+        for (int p = 0; p < TR; ++p) sacc += L.GY[p * L.XS + o];
+      }
+      L.PM[idx] += sacc;
+    }
+    tab_dense(L.GY, L.XS, d, s.Wi, nullptr, L.GB, L.GS, d, 0, 1, L.Wl, TR);
+    // ---- tail backward: grads wrt the MLP output -> GA; g_y second half and g_z first half -> GY (g_x no longer needed)
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      const float gz = L.GB[p * L.GS + c];
+      if (c < Ch) { L.GY[p * L.XS + c] = gz; continue; }
+      const int j = c - Ch;
+      if (s.additive) {
+        L.GA[p * L.GS + j] = -gz;
+        L.GY[p * L.XS + c] = gz;
+      } else {
+        const float sc = sigmoidf(L.O[p * L.OS + 2 * j + 1] + 2.f), y2 = L.Y[p * L.XS + c];
+        const float gl = (m < s.B && gld) ? gld[m] : 0.f;
+        L.GA[p * L.GS + 2 * j] = -gz;
+        L.GA[p * L.GS + 2 * j + 1] = m < s.B ? -gz * y2 * (1.f - sc) / sc - gl * (1.f - sc) : 0.f;
+        L.GY[p * L.XS + c] = gz / sc;
+      }
+    }
+    __syncthreads();
+    const float* g = tab_mlp_backward(s, L);
+    // g = grad wrt IN0 = (z1 | cond)
+    for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+      const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+      if (c < Ch) L.GY[p * L.XS + c] += g[p * L.GS + c];
+      else if (gcond && m < s.B) gcond[(long)m * s.ncond + (c - Ch)] += g[p * L.GS + c];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      if (m < s.B) gy[(long)m * d + c] = L.GY[p * L.XS + c];
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NP; i += blockDim.x) part[(long)blockIdx.x * NP + i] = L.Pl[i];
@@ -414,6 +526,23 @@ int nfk_tab_bwd(const nfk_tab_step* s, const nfk_tab_grads* g, const float* x, c
                             160 * 1024);
   const int nb = tab_blocks(*s, true);
   hipLaunchKernelGGL(tab_bwd_kernel, dim3(nb), dim3(256), lds, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
+  NFK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tab_reduce_kernel, dim3(ceil_div(tab_param_floats(*s), 256)), dim3(256), 0, st, *s, *g, part, nb);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int nfk_tab_inv_bwd(const nfk_tab_step* s, const nfk_tab_grads* g, const float* y, const float* cond,
+                    const float* g_x, const float* g_ld, float* g_y, float* g_cond, float* part, float* part_mix,
+                    void* stream) {
+  size_t lds;
+  if (tab_check(*s, true, &lds) != NFK_OK || !s->Wi) return NFK_ERR_ARG;
+  if (s->B == 0) return NFK_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_inv_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int nb = tab_blocks(*s, true);
+  hipLaunchKernelGGL(tab_inv_bwd_kernel, dim3(nb), dim3(256), lds, st, *s, y, cond, g_x, g_ld, g_y, g_cond, part,
+                     part_mix);
   NFK_LAUNCH_CHECK();
   hipLaunchKernelGGL(tab_reduce_kernel, dim3(ceil_div(tab_param_floats(*s), 256)), dim3(256), 0, st, *s, *g, part, nb);
   NFK_LAUNCH_CHECK();

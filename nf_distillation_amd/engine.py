@@ -296,9 +296,16 @@ class FlowEngine:
         res = _EncodeFn.apply(self, x, logdet, noise, y_onehot, *self.params())
         return list(res[:-1]), res[-1]
 
-    @torch.no_grad()
     def decode(self, z, y_onehot, temperature, eps=None):
-        """Reverse pass (no autograd).  `eps`: {layer index: N(0,1) tensor [B,C/2,H,W]} for Split2d."""
+        """Reverse pass.  `eps`: {layer index: N(0,1) tensor [B,C/2,H,W]} for Split2d.  1-D flows carry gradients
+        (the perceptual branch of the tabular distillation loss, pl_module.py:229-243) when autograd is recording and a
+        parameter or `z` requires them; the 2-D reverse pass is sampling-only (its perceptual weight is 0 upstream)."""
+        if self.is_1d and torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.params())):
+            return list(_DecodeFn.apply(self, z, y_onehot, *self.params()))
+        with torch.no_grad():
+            return self._decode_nograd(z, y_onehot, temperature, eps)
+
+    def _decode_nograd(self, z, y_onehot, temperature, eps=None):
         st = self._ensure_for_decode(z)
         self._refresh(st, True)
         lib, s = capi.lib(), capi.stream()
@@ -386,6 +393,72 @@ class _Scratch:
                 self.bufs[i] = torch.empty(n, device=self.device, dtype=torch.float32)
             out.append(self.bufs[i])
         return out
+
+
+class _DecodeFn(torch.autograd.Function):
+    """The reverse pass of a 1-D FlowNet (models/kd_flows.py:55-73) with gradients, as one autograd node: parameter
+    gradients are accumulated straight into `.grad` (as _EncodeFn does); returns every intermediate tensor."""
+
+    @staticmethod
+    def forward(ctx, eng, z, y_onehot, *params):
+        st = eng._ensure_for_decode(z)
+        eng._refresh(st, True)
+        ctx.set_materialize_grads(False)
+        cur = z.detach().to(torch.float32).contiguous()
+        outs, saved = [], []
+        for r in reversed(st["recs"]):
+            r.tab.part_mix_inv = None
+            cur, sv = r.tab.inverse(cur, y_onehot, need=True)
+            outs.append(cur)
+            saved.append(sv)
+        ctx.eng, ctx.saved, ctx.y_onehot = eng, saved, y_onehot
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        eng = ctx.eng
+        st = eng.state
+        lib, s = capi.lib(), capi.stream()
+        recs = st["recs"]
+        dev = ctx.saved[0][0].device
+        B = ctx.saved[0][0].shape[0]
+        for p in eng.params():
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+        want_gy = ctx.needs_input_grad[2]
+        g, g_y = None, None
+        n_steps = len(recs)
+        for n in reversed(range(n_steps)):   # decode order n handled recs[n_steps - 1 - n]
+            r = recs[n_steps - 1 - n]
+            go = g_outs[n]
+            if go is not None:
+                go = go.to(torch.float32).contiguous()
+                g = go if g is None else g + go
+            if g is None:
+                continue
+            g, gc = r.tab.inverse_backward(ctx.saved[n], g, want_gy)
+            if gc is not None:
+                g_y = gc if g_y is None else g_y + gc
+        pg = []
+        for r in recs:
+            d = PrepGrad()
+            if r.tab.part_mix_inv is not None:
+                if r.C > 74:
+                    raise RuntimeError("reverse-pass gradients support at most 74 features per step")
+                d.part, d.nparts = r.tab.part_mix_inv.data_ptr(), r.tab.nblk
+                an, ic = r.mod.actnorm, r.mod.invconv
+                d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
+                if ic.LU_decomposed:
+                    d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
+                else:
+                    d.g_weight = ptr(ic.weight.grad)
+            pg.append(d)
+        if any(d.nparts > 0 for d in pg):
+            grad_dev = capi.struct_array_to_device(pg, dev)
+            check(lib.nfk_prep_inv_bwd(ptr(st["prep_dev"]), ptr(grad_dev), st["n_prep"], None, B, s), "nfk_prep_inv_bwd")
+            ctx.keep = (grad_dev,)
+        gz = g if ctx.needs_input_grad[1] else None
+        return (None, gz, g_y if want_gy else None) + (None,) * len(eng.params())
 
 
 class _EncodeFn(torch.autograd.Function):

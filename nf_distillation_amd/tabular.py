@@ -32,6 +32,7 @@ class TabStep:
         self.nblk = lib.nfk_tab_bwd_blocks(C.byref(s))
         self.nparam = lib.nfk_tab_param_floats(C.byref(s))
         self.part_mix = None
+        self.part_mix_inv = None
 
     def _cond(self, y_onehot, forward):
         # forward conditions on "y given", reverse on "model has condition features" (models/flows.py:152 vs :177)
@@ -52,12 +53,30 @@ class TabStep:
         check(lib.nfk_tab_fwd(C.byref(self.cs), ptr(x), ptr(cond), ptr(ld), ptr(out), ptr(ld_out), s), "nfk_tab_fwd")
         return out, ld_out, ((x, cond) if need else None)
 
-    def inverse(self, y, y_onehot):
+    def inverse(self, y, y_onehot, need=False):
         lib, s = capi.lib(), capi.stream()
         cond = self._cond(y_onehot, False)
         out = torch.empty_like(y)
         check(lib.nfk_tab_inv(C.byref(self.cs), ptr(y), ptr(cond), None, ptr(out), None, s), "nfk_tab_inv")
-        return out
+        return (out, (y, cond)) if need else out
+
+    def inverse_backward(self, saved, g_x, want_gcond):
+        """Backward of `inverse` (reverse pass with gradients, pl_module.py:229-243): g_x = dL/d(output) -> g_y."""
+        lib, s = capi.lib(), capi.stream()
+        y, cond = saved
+        blk = self.layer.block
+        g = TabGrads()
+        for k, li in enumerate(_LIN):
+            g.gW[k], g.gb[k] = ptr(blk[li].weight.grad), ptr(blk[li].bias.grad)
+        d = self.cs.d
+        part = torch.empty(self.nblk * self.nparam, device=y.device, dtype=torch.float32)
+        self.part_mix_inv = torch.empty(self.nblk * (d * d + d), device=y.device, dtype=torch.float32)
+        gy = torch.empty_like(y)
+        gcond = torch.zeros_like(cond) if (cond is not None and want_gcond) else None
+        check(lib.nfk_tab_inv_bwd(C.byref(self.cs), C.byref(g), ptr(y), ptr(cond), ptr(g_x), None, ptr(gy), ptr(gcond),
+                                  ptr(part), ptr(self.part_mix_inv), s), "nfk_tab_inv_bwd")
+        self._keep_inv = part
+        return gy, gcond
 
     def backward(self, saved, g_out, g_ld, want_gcond):
         lib, s = capi.lib(), capi.stream()

@@ -188,9 +188,13 @@ class DistillationStep:
     """One optimisation step of teacher->student distillation (see module docstring)."""
 
     def __init__(self, student, teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, weight_decay=0.0,
-                 clip_norm=30.0, process_group=None, bucket_bytes=16 << 20, student_is_1d=False):
+                 clip_norm=30.0, process_group=None, bucket_bytes=16 << 20, student_is_1d=False,
+                 perceptual_weight=0.0):
         self.student, self.teacher = student, teacher
-        self.w_nll, self.w_kd = nll_weight, kd_weight
+        self.w_nll, self.w_kd, self.w_perc = nll_weight, kd_weight, perceptual_weight
+        if perceptual_weight > 0 and (teacher is None or not getattr(student, "is_1d", False)):
+            # images use VGG features upstream (models/vgg_loss.py), with weight 0 in every image config
+            raise ValueError("the perceptual (L1) branch is the tabular one: it needs 1-D flows and a teacher")
         if teacher is not None:
             for p in teacher.parameters():
                 p.requires_grad_(False)
@@ -222,7 +226,28 @@ class DistillationStep:
             t_z, _, _ = self.teacher(x, None, noise=noise_teacher)
         return t_z
 
-    def forward_losses(self, x, noise_student=None, noise_teacher=None):
+    def perceptual_l1(self, x, latent=None, y_onehot=None):
+        """pl_module.py:229-243, 283-299 for tabular data: student (with gradients) and teacher decode the same latent
+        ~ student prior at temperature 0.7; per-sample mean |x_s - x_t|, NaN rows zeroed."""
+        from .modules import gaussian_sample
+        if latent is None:
+            mean, logs = self.student.prior(x, y_onehot)
+            latent = gaussian_sample(mean, logs, 1)
+        s_x = self.student(z=latent, temperature=0.7, reverse=True, y_onehot=y_onehot)[-1]
+        with torch.no_grad():
+            t_x = self.teacher(z=latent, temperature=0.7, reverse=True, y_onehot=y_onehot)[-1]
+        per = (s_x - t_x).abs().flatten(1).mean(1)
+        return torch.where(torch.isnan(per), torch.zeros_like(per), per)
+
+    def forward_losses(self, x, noise_student=None, noise_teacher=None, latent=None):
+        out = self._nll_kd_losses(x, noise_student, noise_teacher)
+        if self.w_perc > 0:
+            per = self.perceptual_l1(x, latent).mean()
+            out["perceptual"] = per
+            out["result_loss"] = out["result_loss"] + self.w_perc * per   # mean_b of a sum = sum of the means
+        return out
+
+    def _nll_kd_losses(self, x, noise_student=None, noise_teacher=None):
         use_teacher = self.w_kd > 0 and self.teacher is not None
         t_z = None
         if use_teacher and self._concurrent:
@@ -260,10 +285,10 @@ class DistillationStep:
 
     # A step = three phases; multi-rank graph replay captures the first and the last separately so that the
     # collective itself is never part of a captured graph.
-    def fwd_bwd(self, x, noise_student=None, noise_teacher=None):
+    def fwd_bwd(self, x, noise_student=None, noise_teacher=None, latent=None):
         self.flat.zero_grad()
         self.reducer.reset()
-        out = self.forward_losses(x, noise_student, noise_teacher)
+        out = self.forward_losses(x, noise_student, noise_teacher, latent)
         out["result_loss"].backward()
         return {k: v.detach() for k, v in out.items()}
 
@@ -278,9 +303,10 @@ class DistillationStep:
         eng = self.student.flow.engine()
         eng.grad_hook = (lambda idx: self.reducer.ready(self.flat.lo_for_layer(idx))) if (on and self.world > 1) else None
 
-    def training_step(self, x, noise_student=None, noise_teacher=None):
-        """x: [B_local, C, H, W] on the GPU (mutated in place by the dequantisation noise, as upstream)."""
-        out = self.fwd_bwd(x, noise_student, noise_teacher)
+    def training_step(self, x, noise_student=None, noise_teacher=None, latent=None):
+        """x: [B_local, C, H, W] on the GPU (mutated in place by the dequantisation noise, as upstream), or [B, d] rows.
+        latent: optional caller-drawn latent of the perceptual branch (tests); default = a draw from the student prior."""
+        out = self.fwd_bwd(x, noise_student, noise_teacher, latent)
         self.allreduce()
         self.optimize()
         return out

@@ -407,10 +407,21 @@ def is_buffer(key: str) -> bool:
     return key == "prior_h" or key.endswith("invconv.p") or key.endswith("invconv.sign_s")
 
 
+def perceptual_l1(student_sd, student_cfg, teacher_sd, teacher_cfg, latent, y_onehot=None):
+    """The perceptual branch for tabular data (pl_module.py:229-243, 283-299 with nn.L1Loss(reduction='none')):
+    both models decode the SAME latent at temperature 0.7 (the student with gradients); per-sample mean |dx|,
+    NaN rows zeroed.  `latent` = gaussian_sample(student prior, 1), drawn by the caller."""
+    s_x = glow_reverse(student_sd, student_cfg, latent, y_onehot, temperature=0.7)[-1]
+    with torch.no_grad():
+        t_x = glow_reverse(teacher_sd, teacher_cfg, latent, y_onehot, temperature=0.7)[-1]
+    per = (s_x - t_x).abs().flatten(1).mean(1)
+    return torch.where(torch.isnan(per), torch.zeros_like(per), per), s_x, t_x
+
+
 def distill_step(student_sd, student_cfg, teacher_sd, teacher_cfg, x, noise_s, noise_t,
-                 opt_state, lr=5e-4, w_nll=0.9, w_kd=0.1, clip=30.0):
+                 opt_state, lr=5e-4, w_nll=0.9, w_kd=0.1, clip=30.0, w_perc=0.0, latent=None):
     """One training step as the reference runs it: student fwd (grad), teacher fwd on the
-    SAME (already noised, in-place) x (no grad), MSE hints, clip, Adam on the student.
+    SAME (already noised, in-place) x (no grad), MSE hints, [perceptual branch], clip, Adam on the student.
     Returns dict of scalars; mutates student_sd and x."""
     names = [k for k in student_sd if not is_buffer(k)]
     for k in names:
@@ -421,6 +432,10 @@ def distill_step(student_sd, student_cfg, teacher_sd, teacher_cfg, x, noise_s, n
     with torch.no_grad():
         t_z, _, _ = glow_forward(teacher_sd, teacher_cfg, x, None, noise_t)
     out = distill_losses(s_z, s_nll, t_z, s_idx, t_idx, w_nll, w_kd)
+    if w_perc > 0:
+        per, _, _ = perceptual_l1(student_sd, student_cfg, teacher_sd, teacher_cfg, latent)
+        out["perceptual"] = per.mean()
+        out["result_loss"] = out["result_loss"] + w_perc * per.mean()   # mean_b of a sum = sum of the means
     out["result_loss"].backward()
     with torch.no_grad():
         params = [student_sd[k] for k in names]

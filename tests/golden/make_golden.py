@@ -137,6 +137,37 @@ def model_case(name, cfg, batch, seed, noise_seed=99):
     save(name, cfg, arrays)
 
 
+def reverse_grad_case(name, cfg, batch, seed):
+    """Reverse (sampling) pass WITH gradients, as the perceptual branch of the tabular distillation loss uses it
+    (pl_module.py:229-243, 283-299): x = model(z=latent, temperature=0.7, reverse=True)[-1],
+    loss = L1(x, target).mean(dim=1).mean(); gradients wrt every parameter and wrt the latent."""
+    model, sd = build(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 23)
+    d = cfg["image_shape"][0]
+    arrays = {f"sd/{k}": v for k, v in sd.items()}
+    y = None
+    if cfg["y_condition"]:
+        y = torch.zeros(batch, cfg["y_classes"])
+        y[torch.arange(batch), torch.randint(0, cfg["y_classes"], (batch,), generator=g)] = 1.0
+        arrays["y"] = y
+    z = torch.randn(batch, d, generator=g).requires_grad_(True)
+    target = torch.randn(batch, d, generator=g)
+    arrays["z"], arrays["target"] = z.detach().clone(), target
+    model.train()
+    outs = model(z=z, y_onehot=y, temperature=0.7, reverse=True)
+    x = outs[-1]
+    per = torch.nn.L1Loss(reduction="none")(x, target).mean(dim=1)
+    loss = per.mean()
+    loss.backward()
+    for i, o in enumerate(outs):
+        arrays[f"rev/{i}"] = o
+    arrays["loss"] = loss
+    arrays["grad_z"] = z.grad
+    for k, p in model.named_parameters():
+        arrays[f"grad/{k}"] = p.grad if p.grad is not None else torch.zeros_like(p)
+    save(name, cfg, arrays)
+
+
 def primitive_case():
     """Per-primitive vectors."""
     g = torch.Generator().manual_seed(3)
@@ -240,6 +271,61 @@ def distill_case():
     save("distill8", {"student": s_cfg, "teacher": t_cfg}, arrays)
 
 
+def distill_tab_case():
+    """Two optimisation steps of the TABULAR distillation step (conf/training/tabular.yaml: nll 0.85, kd 0.05 (mse),
+    perceptual 0.1 (l1)): NFModel.forward + loss (pl_module.py:198-320) restated on the reference's models, including
+    the perceptual branch -- reverse passes of student (with gradients) and teacher from a latent drawn from the
+    student's prior -- then clip 30 + Adam.  The drawn latents are stored (the product takes them as an argument)."""
+    tab = dict(L=1, is_1d=True, y_classes=0, hidden_channels=32, image_shape=[6])
+    s_cfg, t_cfg = base_cfg(K=3, **tab), base_cfg(K=5, **tab)
+    student, s_sd = build(s_cfg, 61)
+    teacher, t_sd = build(t_cfg, 63)
+    teacher.eval()
+    s_idx, t_idx = [1, 2], [3, 4]      # NFModel._get_kd_indices for 1-D K=3 / K=5 (pl_module.py:81-110)
+    opt = torch.optim.Adam(student.parameters(), lr=5e-4, weight_decay=0)
+    arrays = {f"s_sd/{k}": v for k, v in s_sd.items()}
+    arrays.update({f"t_sd/{k}": v for k, v in t_sd.items()})
+    arrays["s_idx"], arrays["t_idx"] = np.array(s_idx), np.array(t_idx)
+    l1 = torch.nn.L1Loss(reduction="none")
+    for step in range(2):
+        g = torch.Generator().manual_seed(80 + step)
+        x = torch.randn(16, 6, generator=g)
+        arrays[f"step{step}/x"] = x.clone()
+        opt.zero_grad()
+        s_z, s_nll, _ = student(x, None)
+        with torch.no_grad():
+            t_z, _, _ = teacher(x, None)
+        kd_val = None
+        for si, ti in zip(s_idx, t_idx):
+            d = torch.nn.functional.mse_loss(s_z[si], t_z[ti], reduction="none")
+            d = d.mean(dim=list(range(d.dim()))[1:])
+            kd_val = d if kd_val is None else kd_val + d
+        kd_val = kd_val / len(s_idx)
+        mean, logs = student.prior(x, y_onehot=None)
+        torch.manual_seed(90 + step)
+        latent = layers.gaussian_sample(mean, logs, 1)
+        arrays[f"step{step}/latent"] = latent.clone()
+        student_x = student(z=latent, temperature=0.7, reverse=True, y_onehot=None)[-1]
+        with torch.no_grad():
+            teacher_x = teacher(z=latent, temperature=0.7, reverse=True, y_onehot=None)[-1]
+        perc = l1(student_x, teacher_x)
+        perc = perc.mean(dim=list(range(perc.dim()))[1:])
+        perc[(torch.isnan(perc)).nonzero(as_tuple=True)[0]] = 0
+        res = (0.85 * s_nll + 0.05 * kd_val + 0.1 * perc).mean()
+        res.backward()
+        gn = torch.nn.utils.clip_grad_norm_(student.parameters(), 30.0)
+        for k, p in student.named_parameters():
+            arrays[f"step{step}/grad/{k}"] = p.grad.clone()
+        opt.step()
+        arrays[f"step{step}/nll"], arrays[f"step{step}/kd"] = s_nll.mean(), kd_val.mean()
+        arrays[f"step{step}/perceptual"], arrays[f"step{step}/loss"] = perc.mean(), res
+        arrays[f"step{step}/grad_norm"] = gn
+        arrays[f"step{step}/student_x"], arrays[f"step{step}/teacher_x"] = student_x, teacher_x
+        for k, v in student.state_dict().items():
+            arrays[f"step{step}/s_sd_after/{k}"] = v.clone()
+    save("distill_tab6", {"student": s_cfg, "teacher": t_cfg}, arrays)
+
+
 def checksum_case(name, cfg, batch, seed):
     """Full-size models: parameters are rebuilt from (shapes, seed) by the tests, only
     per-layer checksums and bpd are stored."""
@@ -260,8 +346,23 @@ def checksum_case(name, cfg, batch, seed):
     save(name, cfg, arrays)
 
 
+def reverse_grad_cases():
+    tab = dict(L=1, is_1d=True, y_classes=0)
+    reverse_grad_case("tab6_revgrad", base_cfg(image_shape=[6], K=2, **tab), 8, 121)
+    reverse_grad_case("tab63_revgrad", base_cfg(image_shape=[63], K=2, **tab), 8, 122)
+    reverse_grad_case("tab6_k5_h32_revgrad", base_cfg(image_shape=[6], K=5, hidden_channels=32, **tab), 16, 123)
+    reverse_grad_case("tab6_additive_nolu_revgrad",
+                      base_cfg(image_shape=[6], K=3, flow_coupling="additive", LU_decomposed=False, **tab), 8, 125)
+    reverse_grad_case("tab5_cond_revgrad", base_cfg(image_shape=[5], K=2, L=1, is_1d=True, y_classes=3,
+                                                    y_condition=True, learn_top=True), 8, 124)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--only-reverse-grad" in sys.argv:   # added after the other fixtures were committed: leaves them untouched
+        reverse_grad_cases()
+        distill_tab_case()
+        sys.exit(0)
     primitive_case()
     model_case("glow8", base_cfg(), 2, 101)
     model_case("glow32", base_cfg(image_shape=[32, 32, 3], hidden_channels=32, L=3), 2, 102)
@@ -277,7 +378,9 @@ if __name__ == "__main__":
     model_case("tab6_k5_h32", base_cfg(image_shape=[6], K=5, hidden_channels=32, **tab), 16, 113)
     model_case("tab5_cond", base_cfg(image_shape=[5], K=2, L=1, is_1d=True, y_classes=3,
                                      y_condition=True, learn_top=True), 8, 114)
+    reverse_grad_cases()
     distill_case()
+    distill_tab_case()
     cifar = dict(image_shape=[32, 32, 3], hidden_channels=512, L=3)
     checksum_case("cifar_k8_full", base_cfg(K=8, **cifar), 4, 201)
     checksum_case("cifar_k32_full", base_cfg(K=32, **cifar), 2, 202)

@@ -178,3 +178,33 @@ def test_tabular_large_batch_round_trip():
         rev = model(z=outs[-1], temperature=1.0, reverse=True)
     assert rel_err(rev[-1].cpu(), x.cpu()) < 1e-4
     assert torch.isfinite(nll).all()
+
+
+REVGRAD_CASES = ["tab6_revgrad", "tab63_revgrad", "tab6_k5_h32_revgrad", "tab6_additive_nolu_revgrad",
+                 "tab5_cond_revgrad"]
+
+
+@pytest.mark.parametrize("name", REVGRAD_CASES)
+def test_tabular_reverse_pass_gradients(name):
+    """Reverse (sampling) pass WITH gradients through the HIP kernels (nfk_tab_inv_bwd + nfk_prep_inv_bwd): the
+    perceptual branch of the tabular distillation loss, pl_module.py:229-243, 283-299.  Samples, the L1 loss and the
+    gradients of every parameter and of the latent against the reference's."""
+    g = Golden(name)
+    model = build(g.cfg, g.group("sd"))
+    z = g.t("z").cuda().requires_grad_(True)
+    y = g.t("y").cuda() if g.has("y") else None
+    outs = model(z=z, y_onehot=y, temperature=0.7, reverse=True)
+    for i, (o, r) in enumerate(zip(outs, g.seq("rev"))):
+        assert rel_err(o.detach().cpu(), r) < 1e-4, (i, rel_err(o.detach().cpu(), r))
+    loss = torch.nn.L1Loss(reduction="none")(outs[-1], g.t("target").cuda()).mean(dim=1).mean()
+    assert rel_err(loss.detach().cpu(), g.t("loss")) < 1e-5
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_err(z.grad.cpu(), g.t("grad_z")) < 1e-3, rel_err(z.grad.cpu(), g.t("grad_z"))
+    for k, p in model.named_parameters():
+        ref = g.t(f"grad/{k}")
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
+        if float(ref.abs().max()) == 0.0:
+            assert float(got.abs().max()) < 1e-6, k
+        else:
+            assert rel_err(got, ref) < 1e-3, (k, rel_err(got, ref))

@@ -179,3 +179,54 @@ def full_shapes(cfg):
             shapes[p + "conv.conv.weight"] = (c, c // 2, 3, 3)
             shapes[p + "conv.conv.bias"] = (c,)
     return shapes
+
+
+REVGRAD_CASES = ["tab6_revgrad", "tab63_revgrad", "tab6_k5_h32_revgrad", "tab6_additive_nolu_revgrad",
+                 "tab5_cond_revgrad"]
+
+
+@pytest.mark.parametrize("name", REVGRAD_CASES)
+def test_reverse_pass_gradients(name):
+    """Reverse (sampling) pass with gradients -- the perceptual branch of the tabular distillation loss
+    (pl_module.py:229-243, 283-299): the oracle's decode under autograd against the reference's gradients."""
+    g = Golden(name)
+    cfg, sd = g.cfg, g.group("sd")
+    trainable = [k for k in sd if not O.is_buffer(k)]
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    z = g.t("z").clone().requires_grad_(True)
+    y = g.t("y") if g.has("y") else None
+    outs = O.glow_reverse(sd, cfg, z, y, temperature=0.7)
+    for o, r in zip(outs, g.seq("rev")):
+        assert rel_err(o, r) < 5e-5
+    loss = (outs[-1] - g.t("target")).abs().mean(dim=1).mean()
+    assert rel_err(loss, g.t("loss")) < 1e-5
+    loss.backward()
+    assert rel_err(z.grad, g.t("grad_z")) < 5e-4
+    for k in trainable:
+        ref = g.t(f"grad/{k}")
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(ref)
+        if float(ref.abs().max()) == 0.0:
+            assert float(got.abs().max()) < 1e-7, k
+        else:
+            assert rel_err(got, ref) < 5e-4, k
+
+
+def test_tabular_distillation_step_with_perceptual_branch():
+    """conf/training/tabular.yaml weights (nll 0.85, kd 0.05, perceptual-l1 0.1): two steps incl. reverse passes."""
+    g = Golden("distill_tab6")
+    s_cfg, t_cfg = g.cfg["student"], g.cfg["teacher"]
+    s_sd, t_sd = g.group("s_sd"), g.group("t_sd")
+    assert O.kd_indices(s_cfg, t_cfg) == (g.t("s_idx").tolist(), g.t("t_idx").tolist())
+    state = {}
+    for step in range(2):
+        p = f"step{step}/"
+        res = O.distill_step(s_sd, s_cfg, t_sd, t_cfg, g.t(p + "x").clone(), None, None, state, w_nll=0.85, w_kd=0.05,
+                             w_perc=0.1, latent=g.t(p + "latent"))
+        assert rel_err(res["nll"], g.t(p + "nll")) < 2e-6
+        assert rel_err(res["kd"], g.t(p + "kd")) < 1e-4
+        assert rel_err(res["perceptual"], g.t(p + "perceptual")) < 1e-5
+        assert rel_err(res["result_loss"], g.t(p + "loss")) < 2e-6
+        assert rel_err(res["grad_norm"], g.t(p + "grad_norm")) < 1e-4
+        for k, ref in g.group(p + "s_sd_after").items():
+            assert float((s_sd[k] - ref).abs().max()) < 2e-5, k
