@@ -68,7 +68,9 @@ static hipStream_t g_aux = nullptr;
 static int g_bwd_mode = 2;
 static hipEvent_t g_ev[4];
 static bool g_ev_ready = false;
+static bool g_aux_forked = false;   // work was sent to the auxiliary stream since the last join
 static void fork_to_aux(hipStream_t main_st, int i) {
+  g_aux_forked = true;
   (void)hipEventRecord(g_ev[i], main_st);
   (void)hipStreamWaitEvent(g_aux, g_ev[i], 0);
 }
@@ -335,6 +337,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   if (ws_st != st && !deferred) {  // join: this step's workspace and weight grads are complete when the call's stream moves on
     (void)hipEventRecord(g_ev[3], ws_st);
     (void)hipStreamWaitEvent(st, g_ev[3], 0);
+    g_aux_forked = false;
   }
   return NFK_OK;
 }
@@ -362,10 +365,11 @@ void* nfk_get_aux_stream(void) { return g_aux; }
 void nfk_set_bwd_mode(int mode) { g_bwd_mode = mode; }
 int nfk_aux_join(void* stream) {
   hipStream_t st = S_(stream);
-  if (g_aux && g_aux != st) {
-    (void)hipEventRecord(g_ev[3], g_aux);
+  if (g_aux && g_aux != st && g_aux_forked) {   // nothing to wait for otherwise (and, while `st` is being captured,
+    (void)hipEventRecord(g_ev[3], g_aux);       // an event of a stream outside the capture must not be waited on)
     (void)hipStreamWaitEvent(st, g_ev[3], 0);
   }
+  g_aux_forked = false;
   return NFK_OK;
 }
 

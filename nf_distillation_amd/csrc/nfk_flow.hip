@@ -23,7 +23,7 @@ namespace nfk {
 constexpr size_t PREP_INV_BWD_LDS = 152 * 1024;   // seven C x C matrices: C <= 74
 constexpr size_t PREP_LDS = 60 * 1024, PREP_BWD_LDS = 60 * 1024;   // dynamic LDS of prep_kernel / prep_bwd_kernel
 // C[n][n] = A * B   (opA/opB: 0 = as is, 1 = transposed)
-__device__ void blk_matmul(const float* A, int ta, const float* B, int tb, float* C, int n) {
+__device__ __forceinline__ void blk_matmul(const float* A, int ta, const float* B, int tb, float* C, int n) {
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx % n;
     float s = 0.f;
@@ -35,7 +35,7 @@ __device__ void blk_matmul(const float* A, int ta, const float* B, int tb, float
 
 // In-place Gauss-Jordan inverse with partial pivoting of A (n x n) using aug[n][2n] scratch.
 // Returns log|det A| (valid in all threads).  sh must hold >= 4 floats/ints.
-__device__ float blk_inverse(const float* A, float* inv, float* aug, int n, float* sh) {
+__device__ __forceinline__ float blk_inverse(const float* A, float* inv, float* aug, int n, float* sh) {
   const int n2 = 2 * n;
   for (int idx = threadIdx.x; idx < n * n2; idx += blockDim.x) {
     const int i = idx / n2, j = idx % n2;
@@ -87,7 +87,7 @@ __device__ float blk_inverse(const float* A, float* inv, float* aug, int n, floa
 }
 
 // scratch layout inside PrepDesc::scratch (floats): T0,T1,T2 [C*C] each, AUG [2*C*C]
-__device__ void build_W(const PrepDesc& d, float* W, float* T0, float* T1, float* sh) {
+__device__ __forceinline__ void build_W(const PrepDesc& d, float* W, float* T0, float* T1, float* sh) {
   const int C = d.C;
   if (d.perm_kind == PERM_LU) {
     for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
@@ -110,19 +110,16 @@ __device__ void build_W(const PrepDesc& d, float* W, float* T0, float* T1, float
   }
 }
 
-__global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ descs, int want_inverse) {
-  __shared__ float sh[32];
-  PrepDesc d = descs[blockIdx.x];
+// `base`: 6 C x C work matrices, either the kernel's dynamic LDS (copy_p: P is staged there too) or the step's global
+// scratch -- two inlined instances, so that the LDS one uses ds_ instructions (see prep_bwd_body).
+__device__ __forceinline__ void prep_body(PrepDesc d, int want_inverse, float* base, const bool copy_p, float* sh) {
   const int C = d.C, CC = C * C;
-  // work matrices (and P) in LDS when six C x C matrices fit the 60 KiB of the launch, else in the step's scratch
-  extern __shared__ __attribute__((aligned(16))) float pf_lds[];
-  const bool in_lds = (size_t)6 * CC * sizeof(float) <= PREP_LDS;
-  float* W = in_lds ? pf_lds : d.scratch;
+  float* W = base;
   float* T0 = W + CC;
   float* T1 = T0 + CC;
   float* AUG = T1 + CC;
   if (C > 0) {
-  if (in_lds && d.perm_kind == PERM_LU) {
+  if (copy_p && d.perm_kind == PERM_LU) {
     float* Pl = W + 5 * CC;
     for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];
     d.p = Pl;   // build_W's first barrier comes before its first use
@@ -171,6 +168,15 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ 
   for (int i = threadIdx.x; i < d.n3; i += blockDim.x) d.es3[i] = expf(3.f * d.l3[i]);
 }
 
+__global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ descs, int want_inverse) {
+  __shared__ float sh[32];
+  const PrepDesc d = descs[blockIdx.x];
+  // work matrices (and P) in LDS when six C x C matrices fit the 60 KiB of the launch, else in the step's scratch
+  extern __shared__ __attribute__((aligned(16))) float pf_lds[];
+  if ((size_t)6 * d.C * d.C * sizeof(float) <= PREP_LDS) prep_body(d, want_inverse, pf_lds, true, sh);
+  else prep_body(d, want_inverse, d.scratch, false, sh);
+}
+
 // In-place reduction of the per-workgroup partial (gWf, gcf) slabs of every step into slab 0:
 // grid = (chunks of 256 elements, steps); element e of all slabs is touched by one thread only.
 __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __restrict__ descs,
@@ -187,7 +193,7 @@ __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __rest
 
 // W = P L U: chain a gradient GW (indexed like W) to (lower, upper, log_s); Gs is added to every g_log_s (the log-det
 // term).  T0, T1, T2, Wk: C*C scratch matrices (T0 / T1 are overwritten with L / U).  Block-wide; accumulates.
-__device__ void prep_lu_chain(const PrepDesc& d, const PrepGrad& g, int C, const float* P, const float* GW, float* Wk,
+__device__ __forceinline__ void prep_lu_chain(const PrepDesc& d, const PrepGrad& g, int C, const float* P, const float* GW, float* Wk,
                               float* T0, float* T1, float* T2, float Gs) {
   const int CC = C * C;
   for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
@@ -211,29 +217,22 @@ __device__ void prep_lu_chain(const PrepDesc& d, const PrepGrad& g, int C, const
 
 // Backward of prep: chain (gWf, gcf, G = sum_b g_logdet[b]) to the raw parameters; accumulates.
 //   part: [nparts][C*C + C] partial sums of  gWf[o][c] = sum_m gz[m][o] x[m][c],  gcf[o] = sum_m gz[m][o]
-__global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
-                                                       const PrepGrad* __restrict__ grads,
-                                                       const float* __restrict__ gld, int B) {
-  __shared__ float sh[32];
-  const PrepDesc d = descs[blockIdx.x];
-  const PrepGrad g = grads[blockIdx.x];
+// `base`: 6 C x C work matrices.  Called once with the kernel's dynamic LDS and once with the step's global scratch so
+// that, after inlining, the LDS instance addresses LDS with ds_ instructions (a pointer selected at run time between the
+// two would make every access a flat load: same latency as global memory).
+__device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad& g, const float* __restrict__ gld, int B,
+                                              float* base, const bool copy_p, float* sh) {
   const int C = d.C, CC = C * C;
-  if (C == 0) return;
-  // the C x C work matrices (and P) live in LDS when six of them fit the 60 KiB the launch provides (C <= 50);
-  // wider steps fall back to the step's global scratch
-  extern __shared__ __attribute__((aligned(16))) float pb_lds[];
-  const bool in_lds = (size_t)6 * CC * sizeof(float) <= PREP_BWD_LDS;
-  float* W = in_lds ? pb_lds : d.scratch;
+  float* W = base;
   float* T0 = W + CC;
   float* T1 = T0 + CC;
   float* AUG = T1 + CC;   // 2*CC floats: use as two more matrices
   float* GW = AUG;
   float* T2 = AUG + CC;
-  const float* P = d.p;
-  if (in_lds && d.perm_kind == PERM_LU) {
+  const float* P = copy_p ? W + 5 * CC : d.p;   // only read for the LU parametrisation
+  if (copy_p && d.perm_kind == PERM_LU) {
     float* Pl = W + 5 * CC;
-    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];
-    P = Pl;   // visible after the first barrier below
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];   // visible after the first barrier below
   }
 
   float G = 0.f;
@@ -267,6 +266,20 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
   }
   __syncthreads();
   if (d.perm_kind == PERM_LU) prep_lu_chain(d, g, C, P, GW, W, T0, T1, T2, G);
+}
+
+__global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
+                                                       const PrepGrad* __restrict__ grads,
+                                                       const float* __restrict__ gld, int B) {
+  __shared__ float sh[32];
+  const PrepDesc d = descs[blockIdx.x];
+  const PrepGrad g = grads[blockIdx.x];
+  if (d.C == 0) return;
+  // the C x C work matrices (and P) live in LDS when six of them fit the 60 KiB the launch provides (C <= 50);
+  // wider steps fall back to the step's global scratch
+  extern __shared__ __attribute__((aligned(16))) float pb_lds[];
+  if ((size_t)6 * d.C * d.C * sizeof(float) <= PREP_BWD_LDS) prep_bwd_body(d, g, gld, B, pb_lds, true, sh);
+  else prep_bwd_body(d, g, gld, B, d.scratch, false, sh);
 }
 
 // Dense-weight variant needs GW after the inverse; done in a second tiny kernel to keep scratch small.
