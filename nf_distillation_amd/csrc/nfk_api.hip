@@ -331,7 +331,9 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   // actnorm + permutation backward: g_x = Wf^T g_z, partial (gWf, gcf) for nfk_prep_bwd
   ChanMixArgs m{};
   m.x = gz; m.ldx = C; m.Wm = s->Wf; m.cv = nullptr; m.z = g_x; m.ldz = C; m.M = M; m.C = C; m.trans = 1;
-  m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = L.S1; m.slab_stride = (long)M * Ch;
+  // conv1's dgrad leaves L.S1 split-K slabs -- or one, when the dual launch ran it through the halo-tile kernel
+  const int S1_used = (dual && narrow_halo_dgrad_active(bf, M, H, W, Ch, hid)) ? 1 : L.S1;
+  m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = S1_used; m.slab_stride = (long)M * Ch;
   m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
   NFK_TRY(launch_chanmix(m, st));
   if (ws_st != st && !deferred) {  // join: this step's workspace and weight grads are complete when the call's stream moves on

@@ -17,6 +17,7 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int BKH = 64;                 // bf16 elements per k-chunk
+static int g_narrow_halo = 1;            // conv1 dgrad through the halo-tile kernel (nfk_set_tuning(3000 / 3001))
 static int g_wgrad_wide_max_splits = 64;
 static int g_wgrad_target_wgs = 768, g_wgrad_max_splits = 64;   // nfk_set_tuning(200 + cap) / (1000 + target)
 static int g_big_tile_min_k = 256;      // see big_tiles(); nfk_set_tuning(100 + v) sets it to v*64 (experiments)
@@ -614,6 +615,151 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Narrow 3x3 conv from a WIDE bf16 input (conv1's dgrad: 512 -> C/2 channels) with the input tile in LDS.
+// The implicit-GEMM kernel above fetches every input element once per tap (9x: 151 MB for the 17 MB gradient of a
+// CIFAR level-1 step, profiles/r01_d_pmc_traffic_bf16.json).  Here a workgroup owns 64 consecutive pixels (raster
+// order over [B*H*W]); the rows m0 - W - 1 ... m0 + 64 + W of the input are staged once, 128 channels at a time, in a
+// swizzled LDS image (double-buffered), and the 9 taps are shifted row reads of that image.  Taps that fall outside the
+// pixel's image read a 16-byte zero slot instead (lane-constant address select); rows outside [0, M) are zero-filled
+// by the buffer loads' bounds check.  The K range of a slice is split over the 4 waves (32 channels each, all taps),
+// reduced through LDS at the end.  Output: fp32 [M][ldo], no split-K slabs.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int nh_rows(int W) { return 64 + 2 * W + 2; }
+__host__ __device__ constexpr size_t nh_lds_bytes(int W, int NT) {
+  return (size_t)2 * nh_rows(W) * 256 + (size_t)4 * 64 * NT * 16 * 4 + 16;
+}
+bool narrow_halo_usable(int bf16, int M, int H, int W, int N, int Cin, int taps) {
+  return bf16 && taps == 9 && N >= 1 && N <= 48 && Cin >= 128 && Cin % 128 == 0 && W >= 1 && W <= 64 && M >= 64 &&
+         nh_lds_bytes(W, (N + 15) / 16) <= 64 * 1024;
+}
+
+template <int NT>
+__device__ __forceinline__ void narrow_halo_body(const ConvGemmArgs& a, const int bx) {
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q4 = lane >> 4;
+  const int W = a.W, HW = a.H * a.W, rows = nh_rows(W), TB = rows * 256;
+  const int m0 = bx * 64, nslices = a.Cin / 128;
+  char* Tbuf = smem_b;
+  float* R = reinterpret_cast<float*>(smem_b + 2 * TB);
+  const int zoff = 2 * TB + 4 * 64 * NT * 16 * 4;   // 16 zero bytes
+  if (tid < 4) reinterpret_cast<unsigned*>(smem_b + zoff)[tid] = 0u;
+  const __amdgpu_buffer_rsrc_t rX = rsrc_of(a.X, (unsigned)((long)a.M * a.ldx * 2));
+  const __amdgpu_buffer_rsrc_t rW = rsrc_of(a.Wt, (unsigned)((long)a.N * a.Kp * 2));
+
+  // staging: piece p = (row, 16-byte slot); rows outside [0, M) read as zeros (bounds check)
+  constexpr int PMAX = (nh_rows(64) * 16 + 255) / 256;
+  const int npieces = rows * 16;
+  u32x4b xreg[PMAX];
+  auto gload = [&](int sl) {
+#pragma unroll
+    for (int t = 0; t < PMAX; ++t) {
+      const int p = tid + 256 * t, row = p >> 4, slot = p & 15;
+      const int m = m0 - W - 1 + row;
+      const bool ok = p < npieces && m >= 0 && m < a.M;
+      xreg[t] = ld16(rX, ok ? (unsigned)((m * a.ldx + sl * 128 + slot * 8) * 2) : OOB);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* T = Tbuf + buf * TB;
+#pragma unroll
+    for (int t = 0; t < PMAX; ++t) {
+      const int p = tid + 256 * t, row = p >> 4, slot = p & 15;
+      if (p < npieces) *reinterpret_cast<u32x4b*>(T + row * 256 + ((slot ^ (row & 15)) << 4)) = xreg[t];
+    }
+  };
+  // B-operand addresses: lane = (output pixel r16 of m-tile mo, channel group q4); this wave's 32 channels of the slice
+  int boff[9][4];
+  {
+    const int slot = wid * 4 + q4;
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+      const int p = mo * 16 + r16, m = m0 + p;
+      const int rem = m % HW, y = rem / W, x = rem - y * W;
+      const bool rok[3] = {y >= 1, true, y + 1 < a.H}, xok[3] = {x >= 1, true, x + 1 < W};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int row = p + W + 1 + dy * W + dx;
+        boff[tap][mo] = (m < a.M && rok[dy + 1] && xok[dx + 1]) ? row * 256 + ((slot ^ (row & 15)) << 4) : -1;
+      }
+    }
+  }
+  // A operands (weights): rows of the [N][Kp] array, k = tap * Cin + slice * 128 + wave * 32 + q4 * 8
+  bf16x8 wreg[2][9][NT];
+  auto wload = [&](int sl, bf16x8 (&f)[9][NT]) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(nt * 16 + r16, a.N - 1);   // clamped rows: never read back
+        f[tap][nt] = __builtin_bit_cast(bf16x8, ld16(rW, (unsigned)((n * a.Kp + tap * a.Cin + sl * 128 + wid * 32 + q4 * 8) * 2)));
+      }
+  };
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  wload(0, wreg[0]);
+  lstore(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int sl = 0; sl < nslices; sl += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cur = sl + h;
+      if (cur >= nslices) break;
+      const bool more = cur + 1 < nslices;
+      if (more) { gload(cur + 1); wload(cur + 1, wreg[h ^ 1]); }
+      const char* T = Tbuf + h * TB;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 fb[4];
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+          const int o = boff[tap][mo];
+          fb[mo] = *reinterpret_cast<const bf16x8*>(o >= 0 ? T + o : smem_b + zoff);
+        }
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt][mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[h][tap][nt], fb[mo], acc[nt][mo], 0, 0, 0);
+      }
+      if (more) lstore(h ^ 1);
+      __syncthreads();
+    }
+  }
+  // cross-wave reduction: rows = output channels (4 per lane: q4*4 + r), columns = pixels (r16)
+  constexpr int NP = NT * 16;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+      *reinterpret_cast<f32x4*>(R + ((wid * 64 + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc[nt][mo];
+  __syncthreads();
+  for (int idx = tid; idx < 64 * a.N; idx += 256) {
+    const int po = idx / a.N, n = idx - po * a.N, m = m0 + po;
+    if (m >= a.M) continue;
+    const float* q = R + po * NP + n;
+    a.out[(long)m * a.ldo + n] = (q[0] + q[64 * NP]) + (q[2 * 64 * NP] + q[3 * 64 * NP]);
+  }
+}
+
+template <int NT, int GTN, int GTM, int GWN, int GWM>
+__global__ void __launch_bounds__(256) dual_halo_dgrad_wgrad_bf16_kernel(ConvGemmArgs d, int nbD, WgradArgs w, int nbW,
+                                                                         int SW) {
+  const int b = blockIdx.x;
+  if (b < nbD) narrow_halo_body<NT>(d, b);
+  else {
+    const int c = b - nbD;
+    wgrad_bf16_body<GTN, GTM, GWN, GWM>(w, c % nbW, SW, c / nbW);
+  }
+}
+
 template <int TN, int TM, int WN, int WM>
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
   wgrad_bf16_body<TN, TM, WN, WM>(a, blockIdx.x, gridDim.y, blockIdx.y);
@@ -704,6 +850,29 @@ int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st) {
   }
 }
 
+template <int NT>
+static int launch_dual_halo(const ConvGemmArgs& d, const WgradArgs& w, int SW, hipStream_t st) {
+  constexpr int BI = 128, BJ = 128;   // the wide weight gradient: wgrad_bf16_body<4, 4, 2, 2>
+  const size_t ldsD = nh_lds_bytes(d.W, NT), ldsW = 2 * WPX * (wg_stride(BI) + wg_stride(BJ));
+  const size_t lds = ldsD > ldsW ? ldsD : ldsW;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_halo_dgrad_wgrad_bf16_kernel<NT, 4, 4, 2, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr = true;
+  }
+  const int nbD = ceil_div(d.M, 64), nbW = ceil_div(w.NI, BI) * ceil_div(w.J, BJ);
+  const int cls = NFK_PROF_DUAL_BWD + 3 * 2 + (d.M >= 8192 ? 0 : (d.M >= 2048 ? 1 : 2));
+  prof_scope_begin(cls, 2.0 * d.M * (double)d.N * d.K + 2.0 * w.M * (double)w.NI * w.J,
+                   2.0 * d.M * d.Cin + 2.0 * d.N * d.K + 4.0 * d.M * d.N + (w.pbf16 ? 2.0 : 4.0) * w.M * w.NI +
+                       (w.qbf16 ? 2.0 : 4.0) * w.M * w.Cq + 4.0 * SW * w.NI * w.J, st);
+  hipLaunchKernelGGL((dual_halo_dgrad_wgrad_bf16_kernel<NT, 4, 4, 2, 2>), dim3(nbD + nbW * SW), dim3(256), lds, st, d, nbD,
+                     w, nbW, SW);
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
 // dgrad + wgrad of one conv in ONE launch.  Returns NFK_ERR_ARG when the pair of tile configurations the two
 // single launchers would pick is not instantiated (the caller then launches them separately).
 int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
@@ -738,6 +907,11 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
   }
   if (!wideD && wideW) {   // conv1: narrow dgrad (split-K slabs), wide weight gradient
     if (d.xf32) return NFK_ERR_ARG;
+    if (g_narrow_halo && d.epi == EPI_RAW && narrow_halo_usable(1, d.M, d.H, d.W, d.N, d.Cin, d.taps)) {
+      if (ntD == 1) return launch_dual_halo<1>(d, w, SW, st);
+      if (ntD == 2) return launch_dual_halo<2>(d, w, SW, st);
+      if (ntD == 3) return launch_dual_halo<3>(d, w, SW, st);
+    }
     if (ntD == 1) return launch_dual<1, 2, 1, 4, false, 4, 4, 2, 2>(d, SD, w, SW, st);
     if (ntD == 2) return launch_dual<2, 2, 1, 4, false, 4, 4, 2, 2>(d, SD, w, SW, st);
     if (ntD == 3) return launch_dual<3, 2, 1, 4, false, 4, 4, 2, 2>(d, SD, w, SW, st);
@@ -747,10 +921,16 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
 }
 
 void set_tuning_bf16(int v) {
-  if (v >= 2000) g_wgrad_wide_max_splits = v - 2000;
+  if (v >= 2900) g_narrow_halo = (v - 2900) & 1;
+  else if (v >= 2000) g_wgrad_wide_max_splits = v - 2000;
   else if (v >= 900) g_wgrad_target_wgs = v - 900;
   else if (v >= 100) g_wgrad_max_splits = v - 100;
   else g_big_tile_min_k = v * 64;
+}
+
+// does the backward of a step with these dims run conv1's dgrad through the halo-tile kernel (one output slab)?
+bool narrow_halo_dgrad_active(int bf16, int M, int H, int W, int N, int Cin) {
+  return g_narrow_halo && narrow_halo_usable(bf16, M, H, W, N, Cin, 9) && N <= 48;
 }
 
 }  // namespace nfk

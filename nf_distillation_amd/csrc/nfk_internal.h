@@ -140,7 +140,8 @@ int conv_mblocks_bf16(int M, int N, int K);
 void set_tuning_bf16(int v);
 int wgrad_splits_bf16(int M, int NI, int J);
 int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st);
-int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st);  // NFK_ERR_ARG: pair not instantiated
+int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st);
+bool narrow_halo_dgrad_active(int bf16, int M, int H, int W, int N, int Cin);   // conv1 dgrad writes ONE slab then  // NFK_ERR_ARG: pair not instantiated
 int repack_batch_bf16(const nfk_repack_desc* descs, int n, hipStream_t st);
 void prof_scope_begin(int cls, double flops, double bytes, hipStream_t st);
 void prof_scope_end(int cls, hipStream_t st);
