@@ -625,13 +625,14 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
 // by the buffer loads' bounds check.  The K range of a slice is split over the 4 waves (32 channels each, all taps),
 // reduced through LDS at the end.  Output: fp32 [M][ldo], no split-K slabs.
 // ------------------------------------------------------------------------------------------
+constexpr size_t NH_MAX_LDS = 80 * 1024;   // two workgroups per CU
 __host__ __device__ constexpr int nh_rows(int W) { return 64 + 2 * W + 2; }
 __host__ __device__ constexpr size_t nh_lds_bytes(int W, int NT) {
   return (size_t)2 * nh_rows(W) * 256 + (size_t)4 * 64 * NT * 16 * 4 + 16;
 }
 bool narrow_halo_usable(int bf16, int M, int H, int W, int N, int Cin, int taps) {
   return bf16 && taps == 9 && N >= 1 && N <= 48 && Cin >= 128 && Cin % 128 == 0 && W >= 1 && W <= 64 && M >= 64 &&
-         nh_lds_bytes(W, (N + 15) / 16) <= 64 * 1024;
+         nh_lds_bytes(W, (N + 15) / 16) <= NH_MAX_LDS;
 }
 
 template <int NT>
@@ -858,7 +859,7 @@ static int launch_dual_halo(const ConvGemmArgs& d, const WgradArgs& w, int SW, h
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_halo_dgrad_wgrad_bf16_kernel<NT, 4, 4, 2, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)NH_MAX_LDS);
     attr = true;
   }
   const int nbD = ceil_div(d.M, 64), nbW = ceil_div(w.NI, BI) * ceil_div(w.J, BJ);
