@@ -24,7 +24,7 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;
   const int Ch = s->C / 2, hid = s->hidden;
   w.S1 = splitk_of(s->bf16, (int)M, Ch, 9 * hid);
-  w.S3w = s->bf16 ? wgrad_splits_bf16((int)M, s->Cout, 9 * hid) : wgrad_splits((int)M, s->Cout, 9 * hid);
+  w.S3w = s->bf16 ? wgrad3_splits_bf16((int)M, s->Cout, hid, s->W) : wgrad_splits((int)M, s->Cout, 9 * hid);
   w.S2w = s->bf16 ? wgrad_splits_bf16((int)M, hid, hid) : wgrad_splits((int)M, hid, hid);
   w.S1w = s->bf16 ? wgrad_splits_bf16((int)M, hid, 9 * Ch) : wgrad_splits((int)M, hid, 9 * Ch);
   // column-sum partials of the two dgrad epilogues: one row pair per m-block of THAT launch's tiling

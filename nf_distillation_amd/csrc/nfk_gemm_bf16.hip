@@ -761,6 +761,122 @@ __global__ void __launch_bounds__(256) dual_halo_dgrad_wgrad_bf16_kernel(ConvGem
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Narrow weight gradient of a 3x3 conv with a WIDE bf16 input (conv3: out[co][tap][c] = sum_px g[px][co] h2[px + d(tap)][c],
+// co <= 16, c = 512) with the input tile in LDS.  The generic kernel above re-reads h2 once per tap (151 of the 170 MB a
+// CIFAR level-1 conv3 dual launch moves).  Here a workgroup owns a slice of 128 input channels and a range of 64-pixel
+// chunks; per chunk the rows m0 - W - 1 ... m0 + 64 + W of the slice are staged once (pixel-major, as they sit in
+// HBM) and the taps are row-shifted transposing reads (ds_read_b64_tr_b16) of that image.  Taps that leave the pixel's
+// image are removed on the OTHER operand: nine copies of the chunk's gradient tile, each with the rows of its invalid
+// pixels zeroed.  Output: split slabs [S][NI][9 * Cq] like the generic kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int WH_SQ = wg_stride(128), WH_SP = wg_stride(16);   // LDS row strides (bytes) of the h2 slice / gradient tiles
+__host__ __device__ constexpr size_t wh_lds_bytes(int W) { return (size_t)nh_rows(W) * WH_SQ + (size_t)9 * 64 * WH_SP; }
+static int g_wgrad_halo = 1;
+static bool wgrad_halo_usable(int M, int NI, int Cq, int taps, int W) {
+  return g_wgrad_halo && taps == 9 && NI >= 1 && NI <= 16 && Cq >= 128 && Cq % 128 == 0 && W >= 1 && W <= 64 && M >= 64 &&
+         M % 64 == 0 && wh_lds_bytes(W) <= 64 * 1024;
+}
+static int wgrad_halo_splits(int M) {
+  const int nchunks = M / 64;
+  return nchunks < 32 ? nchunks : 32;
+}
+
+__device__ __forceinline__ void wgrad_halo_body(const WgradArgs& a, const int bx, const int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int W = a.W, HW = a.H * a.W, rows = nh_rows(W);
+  const int nsl = a.Cq / 128, sl = bx % nsl, z = bx / nsl;
+  const int nchunks = a.M / 64;
+  const int c_begin = (int)((long)nchunks * z / S), c_end = (int)((long)nchunks * (z + 1) / S);
+  char* T = smem_b;                       // [rows][WH_SQ]: row r = pixel m0 - W - 1 + r, 128 channels
+  char* P9 = smem_b + rows * WH_SQ;       // [9][64][WH_SP]: gradient tile per tap, invalid pixels zeroed
+  const __amdgpu_buffer_rsrc_t rP = rsrc_of(a.P, (unsigned)((long)a.M * a.ldp * 4));
+  const __amdgpu_buffer_rsrc_t rQ = rsrc_of(a.Q, (unsigned)((long)a.M * a.ldq * 2));
+  constexpr int PMAX = (nh_rows(64) * 16 + 255) / 256;
+  const int npieces = rows * 16;
+  u32x4b qreg[PMAX];
+  float preg[8];
+  // gradient tile: thread (pixel p = tid >> 1, half = tid & 1) holds 8 output channels of one pixel (tid < 128)
+  const int pp = tid >> 1, ph = tid & 1;
+  auto gload = [&](int chunk) {
+    const int m0 = chunk * 64;
+#pragma unroll
+    for (int t = 0; t < PMAX; ++t) {
+      const int p = tid + 256 * t, row = p >> 4, slot = p & 15;
+      const int m = m0 - W - 1 + row;
+      const bool ok = p < npieces && m >= 0 && m < a.M;
+      qreg[t] = ld16(rQ, ok ? (unsigned)((m * a.ldq + sl * 128 + slot * 8) * 2) : OOB);
+    }
+    if (tid < 128) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int co = ph * 8 + e;
+        preg[e] = ld4f(rP, co < a.NI ? (unsigned)(((m0 + pp) * a.ldp + co) * 4) : OOB);
+      }
+    }
+  };
+  auto lstore = [&](int chunk) {
+#pragma unroll
+    for (int t = 0; t < PMAX; ++t) {
+      const int p = tid + 256 * t, row = p >> 4, slot = p & 15;
+      if (p < npieces) *reinterpret_cast<u32x4b*>(T + row * WH_SQ + slot * 16) = qreg[t];
+    }
+    if (tid < 128) {
+      const int m = chunk * 64 + pp, rem = m % HW, y = rem / W, x = rem - y * W;
+      const bool rok[3] = {y >= 1, true, y + 1 < a.H}, xok[3] = {x >= 1, true, x + 1 < W};
+      const u32x4b v = {pack2(preg[0], preg[1]), pack2(preg[2], preg[3]), pack2(preg[4], preg[5]), pack2(preg[6], preg[7])};
+      const u32x4b zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        *reinterpret_cast<u32x4b*>(P9 + (tap * 64 + pp) * WH_SP + ph * 16) = (rok[tap / 3] && xok[tap % 3]) ? v : zero;
+    }
+  };
+  // wave w: channel tiles 2w, 2w+1 of the slice's eight, all nine taps
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (c_begin < c_end) gload(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();            // the previous chunk's fragments have been read
+    lstore(c);
+    __syncthreads();
+    if (c + 1 < c_end) gload(c + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const char* Tt = T + (W + 1 + dy * W + dx) * WH_SQ;   // row of output pixel 0 for this tap
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 fa = tr_frag(P9 + tap * 64 * WH_SP, WH_SP, 0, ks, lane);
+        const bf16x8 fb0 = tr_frag(Tt, WH_SQ, wid * 32, ks, lane);
+        const bf16x8 fb1 = tr_frag(Tt, WH_SQ, wid * 32 + 16, ks, lane);
+        acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb0, acc[tap][0], 0, 0, 0);
+        acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb1, acc[tap][1], 0, 0, 0);
+      }
+    }
+  }
+  const int iq = (lane >> 4) * 4, jl = lane & 15;
+  float* outp = a.out + (long)z * a.slab_stride;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int j = tap * a.Cq + sl * 128 + wid * 32 + ct * 16 + jl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (iq + r < a.NI) outp[(long)(iq + r) * a.J + j] = acc[tap][ct][r];
+    }
+}
+
+template <int CTN, int CTM, int CWN, int CWM, bool XF32>
+__global__ void __launch_bounds__(256) dual_dgrad_wgradhalo_bf16_kernel(ConvGemmArgs d, int nbD, int SD, WgradArgs w,
+                                                                        int SW) {
+  const int b = blockIdx.x;
+  if (b < nbD * SD) conv_gemm_bf16_body<CTN, CTM, CWN, CWM, XF32>(d, b % nbD, SD, b / nbD);
+  else wgrad_halo_body(w, b - nbD * SD, SW);
+}
+
 template <int TN, int TM, int WN, int WM>
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgradArgs a) {
   wgrad_bf16_body<TN, TM, WN, WM>(a, blockIdx.x, gridDim.y, blockIdx.y);
@@ -825,6 +941,11 @@ static int launch_wgrad_bf16(const WgradArgs& a, int S, hipStream_t st, int cls)
   return NFK_OK;
 }
 
+// split count of the conv3-type weight gradient of a step (NI = Cout, J = 9 * Cq): the halo-tile kernel's when it applies
+int wgrad3_splits_bf16(int M, int NI, int Cq, int W) {
+  return wgrad_halo_usable(M, NI, Cq, 9, W) ? wgrad_halo_splits(M) : wgrad_splits_bf16(M, NI, 9 * Cq);
+}
+
 int wgrad_splits_bf16(int M, int NI, int J) {
   const int tiles = (NI > 96 ? ceil_div(NI, 128) : 1) * ceil_div(J, 128);
   const int nchunks = ceil_div(M, WPX);
@@ -849,6 +970,29 @@ int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st) {
     case 4: return launch_wgrad_bf16<4, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
     default: return launch_wgrad_bf16<6, 2, 1, 4>(a, S, st, NFK_PROF_WGRAD_NARROW);
   }
+}
+
+template <int CTN, int CTM, int CWN, int CWM>
+static int launch_dual_wgradhalo(const ConvGemmArgs& d, int SD, const WgradArgs& w, int SW, hipStream_t st) {
+  constexpr int BN = 16 * CTN * CWN, BM = 16 * CTM * CWM;
+  const size_t ldsD = 2 * (BN + BM) * 128, ldsW = wh_lds_bytes(w.W);
+  const size_t lds = ldsD > ldsW ? ldsD : ldsW;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_dgrad_wgradhalo_bf16_kernel<CTN, CTM, CWN, CWM, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr = true;
+  }
+  const int nbD = ceil_div(d.N, BN) * ceil_div(d.M, BM), nbW = (w.Cq / 128) * SW;
+  const int cls = NFK_PROF_DUAL_BWD + (d.M >= 8192 ? 0 : (d.M >= 2048 ? 1 : 2));
+  prof_scope_begin(cls, 2.0 * d.M * (double)d.N * d.K + 2.0 * w.M * (double)w.NI * w.J,
+                   4.0 * d.M * d.Cin + 2.0 * d.N * d.K + (d.obf16 ? 2.0 : 4.0 * SD) * d.M * d.N + 4.0 * w.M * w.NI +
+                       2.0 * w.M * w.Cq + 4.0 * SW * w.NI * w.J, st);
+  hipLaunchKernelGGL((dual_dgrad_wgradhalo_bf16_kernel<CTN, CTM, CWN, CWM, true>), dim3(nbD * SD + nbW), dim3(256), lds, st,
+                     d, nbD, SD, w, SW);
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
 }
 
 template <int NT>
@@ -890,6 +1034,8 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
   const int ntD = ceil_div(d.N, 16), ntW = ceil_div(w.NI, 16);
   if (wideD && !wideW) {   // conv3: wide dgrad (fp32 gradient in), narrow weight gradient
     if (!d.xf32) return NFK_ERR_ARG;
+    if (!w.pbf16 && w.qbf16 && wgrad_halo_usable(w.M, w.NI, w.Cq, w.taps, w.W) && SW == wgrad_halo_splits(w.M))
+      return bigD ? launch_dual_wgradhalo<4, 4, 2, 2>(d, SD, w, SW, st) : launch_dual_wgradhalo<2, 2, 2, 2>(d, SD, w, SW, st);
     if (bigD) {
       if (ntW == 1) return launch_dual<4, 4, 2, 2, true, 1, 2, 1, 4>(d, SD, w, SW, st);
       if (ntW == 2) return launch_dual<4, 4, 2, 2, true, 2, 2, 1, 4>(d, SD, w, SW, st);
@@ -922,7 +1068,8 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
 }
 
 void set_tuning_bf16(int v) {
-  if (v >= 2900) g_narrow_halo = (v - 2900) & 1;
+  if (v >= 2910) g_wgrad_halo = (v - 2910) & 1;
+  else if (v >= 2900) g_narrow_halo = (v - 2900) & 1;
   else if (v >= 2000) g_wgrad_wide_max_splits = v - 2000;
   else if (v >= 900) g_wgrad_target_wgs = v - 900;
   else if (v >= 100) g_wgrad_max_splits = v - 100;

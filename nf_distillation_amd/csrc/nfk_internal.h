@@ -139,6 +139,7 @@ int conv_splitk_bf16(int M, int N, int K, int epi);
 int conv_mblocks_bf16(int M, int N, int K);
 void set_tuning_bf16(int v);
 int wgrad_splits_bf16(int M, int NI, int J);
+int wgrad3_splits_bf16(int M, int NI, int Cq, int W);
 int wgrad_gemm_bf16(WgradArgs a, int S, hipStream_t st);
 int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st);
 bool narrow_halo_dgrad_active(int bf16, int M, int H, int W, int N, int Cin);   // conv1 dgrad writes ONE slab then  // NFK_ERR_ARG: pair not instantiated

@@ -132,6 +132,7 @@ def _grads_with(mode, halo, g, cfg, sd, x, noise):
     lib = capi.lib()
     lib.nfk_set_bwd_mode(mode)
     lib.nfk_set_tuning(3001 if halo else 3000)   # conv1 dgrad through the halo-tile kernel or the split-K GEMM
+    lib.nfk_set_tuning(3011 if halo else 3010)   # conv3 weight gradient through the halo-tile kernel or the generic one
     try:
         model = build(cfg, sd)
         outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
@@ -141,6 +142,7 @@ def _grads_with(mode, halo, g, cfg, sd, x, noise):
     finally:
         lib.nfk_set_bwd_mode(2)
         lib.nfk_set_tuning(3001)
+        lib.nfk_set_tuning(3011)
 
 
 def test_dual_dgrad_wgrad_launch_is_bit_identical():
@@ -158,10 +160,10 @@ def test_dual_dgrad_wgrad_launch_is_bit_identical():
             assert torch.equal(res[0][k], other[k]), k
 
 
-def test_halo_tile_dgrad_agrees_with_split_k_gemm():
-    """conv1's dgrad through the halo-tile kernel (input tile staged once in LDS, 9 taps as shifted rows) against the
-    implicit-GEMM kernel with split-K slabs: same products, other summation order -- a few bf16 roundings of the
-    downstream gradients flip, nothing more."""
+def test_halo_tile_kernels_agree_with_generic_gemms():
+    """conv1's dgrad and conv3's weight gradient through the halo-tile kernels (wide input tile staged once in LDS, 9 taps
+    as shifted rows) against the implicit-GEMM kernels that fetch the input once per tap: same products, other
+    summation order -- a few bf16 roundings of the downstream gradients flip, nothing more."""
     g = Golden("cifar_k8_full")
     cfg = g.cfg
     sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
