@@ -174,8 +174,39 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs& a, const
     gload(c_begin);
     lstore(0);
   }
-  __syncthreads();
   const int r16 = lane & 15, q4 = lane >> 4;
+  // dgrad epilogue operand (the layer's saved post-ReLU activation at this lane's outputs): requested now, so that its
+  // round trip runs under the k loop instead of after it (short-K dgrads are little more than their epilogue)
+  bf16x4 hpre[TN][TM];
+  const bool hvec = a.epi == EPI_DGRAD && (a.ldh & 3) == 0 && (a.N & 3) == 0;
+  if (hvec) {
+    const __amdgpu_buffer_rsrc_t rH = rsrc_of(a.hprev, (unsigned)((long)a.M * a.ldh * 2));
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int n = n0 + wn * 16 * TN + tn * 16 + q4 * 4, m = m0 + wm * 16 * TM + tm * 16 + r16;
+        const u32x2b v = __builtin_amdgcn_raw_buffer_load_b64(rH, (m < a.M && n + 3 < a.N) ? (int)((m * a.ldh + n) * 2) : (int)OOB, 0, 0);
+        hpre[tn][tm] = __builtin_bit_cast(bf16x4, v);
+      }
+  }
+  // per-channel epilogue constants: also requested before the k loop
+  f32x4 e0v[TN], e1v[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * 16 * TN + tn * 16 + q4 * 4;
+    e0v[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    e1v[tn] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (a.epi != EPI_RAW) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) {
+          if (a.epi == EPI_AN_RELU) e0v[tn][r] = a.e0[n + r];
+          e1v[tn][r] = a.e1[n + r];
+        }
+    }
+  }
+  __syncthreads();
   for (int c = c_begin; c < c_end; ++c) {
     const int buf = (c - c_begin) & 1;
     if (c + 1 < c_end) gload(c + 1);
@@ -209,15 +240,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs& a, const
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + wn * 16 * TN + tn * 16 + nq;
-    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {1.f, 1.f, 1.f, 1.f};
-    if (a.epi != EPI_RAW) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n + r < a.N) {
-          if (a.epi == EPI_AN_RELU) e0[r] = a.e0[n + r];
-          e1[r] = a.e1[n + r];
-        }
-    }
+    const f32x4 e0 = e0v[tn], e1 = e1v[tn];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * 16 * TM + tm * 16 + mi;
@@ -229,7 +252,10 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs& a, const
       } else if (a.epi == EPI_DGRAD) {
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         const __bf16* hp = reinterpret_cast<const __bf16*>(a.hprev) + (long)m * a.ldh + n;
-        if (n + 3 < a.N && ((a.ldh & 3) == 0)) {
+        if (hvec) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (float)hpre[tn][tm][r];
+        } else if (n + 3 < a.N && ((a.ldh & 3) == 0)) {
           const bf16x4 hb = *reinterpret_cast<const bf16x4*>(hp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = (float)hb[r];
