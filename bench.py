@@ -226,8 +226,8 @@ def main():
         # fetch correction, tools/pmc_traffic.py) -- bench.py cannot collect counters itself; null if the profile does
         # not hold this kernel
         traffic, traffic_src = None, None
-        sym = {"<*,1,*>": "nfk::fused2_step_fwd_kernel<3, 1, 4>", "<*,2,*>": "nfk::fused2_step_fwd_kernel<2, 2, 8>",
-               "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16>"}
+        sym = {"<*,1,*>": "nfk::fused2_step_fwd_kernel<3, 1, 4, 1>", "<*,2,*>": "nfk::fused2_step_fwd_kernel<2, 2, 8, 4>",
+               "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>"}
         pmc_file = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_bf16.json")
         if args.dtype == "bf16" and os.path.exists(pmc_file):
             kern = json.load(open(pmc_file)).get("kernels", {})
