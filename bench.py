@@ -97,6 +97,8 @@ def main():
                          "student's step on batch t (nf_distillation_amd/pipeline.py; same values, every call still "
                          "does one teacher forward + one student forward/backward + one optimiser step)")
     ap.add_argument("--tuning", type=int, default=None, help="experiment knob: nfk_set_tuning(v)")
+    ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_set_bwd_mode(v) (0: dgrad and wgrad as "
+                                                                 "separate launches, 2: one launch per conv, default)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "
@@ -122,6 +124,8 @@ def main():
 
     if args.tuning is not None:
         capi.lib().nfk_set_tuning(args.tuning)
+    if args.bwd_mode is not None:
+        capi.lib().nfk_set_bwd_mode(args.bwd_mode)
     student, teacher = make_models(device)
     student.set_compute_dtype(args.dtype)
     teacher.set_compute_dtype(args.dtype)

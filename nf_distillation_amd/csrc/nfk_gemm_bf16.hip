@@ -803,9 +803,10 @@ static bool wgrad_halo_usable(int M, int NI, int Cq, int taps, int W) {
   return g_wgrad_halo && taps == 9 && NI >= 1 && NI <= 16 && Cq >= 128 && Cq % 128 == 0 && W >= 1 && W <= 64 && M >= 64 &&
          M % 64 == 0 && wh_lds_bytes(W) <= 64 * 1024;
 }
+static int g_wgrad_halo_max_splits = 32;   // nfk_set_tuning(3100 + n)
 static int wgrad_halo_splits(int M) {
   const int nchunks = M / 64;
-  return nchunks < 32 ? nchunks : 32;
+  return nchunks < g_wgrad_halo_max_splits ? nchunks : g_wgrad_halo_max_splits;
 }
 
 __device__ __forceinline__ void wgrad_halo_body(const WgradArgs& a, const int bx, const int S) {
@@ -1094,7 +1095,8 @@ int dual_dgrad_wgrad_bf16(ConvGemmArgs d, WgradArgs w, int SW, hipStream_t st) {
 }
 
 void set_tuning_bf16(int v) {
-  if (v >= 2910) g_wgrad_halo = (v - 2910) & 1;
+  if (v >= 3000) g_wgrad_halo_max_splits = v - 3000;
+  else if (v >= 2910) g_wgrad_halo = (v - 2910) & 1;
   else if (v >= 2900) g_narrow_halo = (v - 2900) & 1;
   else if (v >= 2000) g_wgrad_wide_max_splits = v - 2000;
   else if (v >= 900) g_wgrad_target_wgs = v - 900;
