@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="strong scaling instead: fixed global batch (SURVEY.md §8d suggests 512), split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -110,6 +112,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    strong = args.global_batch is not None
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of ranks")
+        args.batch = args.global_batch // world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -180,7 +187,7 @@ def main():
         "metric": "train images/sec Glow CIFAR-10 distillation step",
         "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "Glow CIFAR-10 32x32 distillation training_step: teacher L=3 K=32 h=512 fwd (no grad) + "
                                "student L=3 K=8 h=512 fwd+bwd + MSE hints + clip 30 + Adam",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
