@@ -113,3 +113,59 @@ def test_tabular_distillation_with_perceptual_branch_matches_reference():
         sd = student.state_dict()
         for k, ref in g.group(p + "s_sd_after").items():
             assert float((sd[k].cpu() - ref).abs().max()) < 3e-5, (i, k)
+
+
+def test_aux_stream_deferred_join_is_bit_identical():
+    """Weight-gradient GEMMs on the auxiliary stream with ONE join per backward (nfk_step2d_bwd_deferred + nfk_aux_join,
+    used when the dual launch is switched off) against everything on one stream: same kernels, same order of sums."""
+    from nf_distillation_amd import capi
+    from nf_distillation_amd.training import DistillationStep
+    g = Golden("distill8")
+    res = []
+    try:
+        capi.lib().nfk_set_bwd_mode(0)
+        for concurrent in (False, True):
+            student = _build(g.cfg["student"], g.group("s_sd"))
+            teacher = _build(g.cfg["teacher"], g.group("t_sd"))
+            student.set_compute_dtype("bf16")
+            teacher.set_compute_dtype("bf16")
+            step = DistillationStep(student, teacher)
+            step.enable_concurrency(concurrent)
+            for i in range(2):
+                p = f"step{i}/"
+                step.training_step(g.t(p + "x").cuda(), g.t(p + "noise_s").cuda(), g.t(p + "noise_t").cuda())
+            torch.cuda.synchronize()
+            step.enable_concurrency(False)
+            res.append({k: v.cpu() for k, v in student.state_dict().items()})
+    finally:
+        capi.lib().nfk_set_bwd_mode(2)
+        capi.lib().nfk_set_aux_stream(None)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_fused_distillation_loss_against_tensor_ops():
+    """nfk_kd_loss_fwd / _bwd against the same expression written with tensor ops (NFModel.loss, pl_module.py:257-320)."""
+    from nf_distillation_amd.training import distillation_loss
+    torch.manual_seed(5)
+    B = 6
+    shapes = [(B, 12, 16, 16), (B, 24, 8, 8), (B, 48, 4, 4), (B, 7)]
+    s_h = [torch.randn(sh, device="cuda").contiguous(memory_format=torch.channels_last) if len(sh) == 4
+           else torch.randn(sh, device="cuda") for sh in shapes]
+    t_h = [torch.randn_like(s) for s in s_h]
+    nll = torch.randn(B, device="cuda")
+    leaves = [s.clone().requires_grad_(True) for s in s_h]
+    nll1 = nll.clone().requires_grad_(True)
+    out = distillation_loss(nll1, leaves, t_h, 0.9, 0.1)
+    out["result_loss"].backward()
+    ref_leaves = [s.clone().requires_grad_(True) for s in s_h]
+    nll2 = nll.clone().requires_grad_(True)
+    kd = sum((a - b).square().flatten(1).mean(1) for a, b in zip(ref_leaves, t_h)) / len(s_h)
+    ref = (0.9 * nll2 + 0.1 * kd).mean()
+    ref.backward()
+    assert rel_err(out["result_loss"].detach().cpu(), ref.detach().cpu()) < 1e-6
+    assert rel_err(out["kd"].cpu(), kd.mean().detach().cpu()) < 1e-6
+    assert rel_err(nll1.grad.cpu(), nll2.grad.cpu()) < 1e-6
+    for a, b in zip(leaves, ref_leaves):
+        assert a.grad.stride() == a.stride()
+        assert rel_err(a.grad.cpu(), b.grad.cpu()) < 1e-6
