@@ -325,8 +325,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
   sg.g_l3 = g->g_l3;
-  if (tail_f.S[0] | tail_f.S[1] | tail_f.S[2]) NFK_TRY(launch_step_tail(sg, tail_f, st));
-  else NFK_TRY(launch_small_grads(sg, st));
+  const bool have_tail = (tail_f.S[0] | tail_f.S[1] | tail_f.S[2]) != 0;
 
   // actnorm + permutation backward: g_x = Wf^T g_z, partial (gWf, gcf) for nfk_prep_bwd
   ChanMixArgs m{};
@@ -335,7 +334,15 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   const int S1_used = (dual && narrow_halo_dgrad_active(bf, M, H, W, Ch, hid)) ? 1 : L.S1;
   m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = S1_used; m.slab_stride = (long)M * Ch;
   m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
-  NFK_TRY(launch_chanmix(m, st));
+  // dual mode: the step tail (slab reductions + per-channel gradients) and this channel mix share one launch
+  if (have_tail) {
+    const int rc = launch_tail_chanmix(sg, tail_f, m, st);
+    if (rc == NFK_ERR_ARG) { NFK_TRY(launch_step_tail(sg, tail_f, st)); NFK_TRY(launch_chanmix(m, st)); }
+    else if (rc != NFK_OK) return rc;
+  } else {
+    NFK_TRY(launch_small_grads(sg, st));
+    NFK_TRY(launch_chanmix(m, st));
+  }
   if (ws_st != st && !deferred) {  // join: this step's workspace and weight grads are complete when the call's stream moves on
     (void)hipEventRecord(g_ev[3], ws_st);
     (void)hipStreamWaitEvent(st, g_ev[3], 0);

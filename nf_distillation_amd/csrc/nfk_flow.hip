@@ -396,7 +396,7 @@ static inline __host__ __device__ int cm_tile_pixels(int C) {
   return tp;
 }
 
-__global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
+__device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C, Cp = (C + 3) & ~3, XS = C + 1, G4 = Cp / 4;
   const int TP = cm_tile_pixels(C);
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
     for (int idx = threadIdx.x; idx < E; idx += blockDim.x) Pl[idx] = 0.f;
   const int ntiles = (a.M + TP - 1) / TP;
   const int p = threadIdx.x / G4, og = threadIdx.x - p * G4;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = bx; tile < ntiles; tile += nblk) {
     const int m0 = tile * TP;
     __syncthreads();
     for (int idx = threadIdx.x; idx < TP * C; idx += blockDim.x) {
@@ -469,10 +469,11 @@ __global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
     }
   }
   if (a.part) {
-    float* part = a.part + (long)blockIdx.x * E;
+    float* part = a.part + (long)bx * E;
     for (int idx = threadIdx.x; idx < E; idx += blockDim.x) part[idx] = Pl[idx];
   }
 }
+__global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) { chanmix_body(a, blockIdx.x, gridDim.x); }
 
 // ==========================================================================================
 // coupling tail (affine / additive), one workgroup per sample
@@ -818,11 +819,11 @@ __global__ void __launch_bounds__(256) small_grads_kernel(SmallGradArgs a) {
 // One launch for everything a FlowStep's backward still owes its parameters once the GEMMs are done: the three
 // split-slab reductions of the weight gradients (wgrad finalize: gradW[co][ci][tap] += sum_s slab[s][co][tap*Cin+ci])
 // and the small per-channel gradients above.  blockIdx.x ranges select the task.
-__global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTailArgs f) {
+__device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const StepTailArgs& f, const int blk) {
   const int nsg = f.sg_blocks * 3;
-  if ((int)blockIdx.x < nsg) {
+  if (blk < nsg) {
     __shared__ float red[2][8][32];
-    const int seg = blockIdx.x / f.sg_blocks, bx = blockIdx.x - seg * f.sg_blocks;
+    const int seg = blk / f.sg_blocks, bx = blk - seg * f.sg_blocks;
     const float* src; int rows, n; float *g0, *g1;
     if (seg == 0) { src = a.col1; rows = a.mb1; n = a.n1; g0 = a.g_l1; g1 = a.g_b1; }
     else if (seg == 1) { src = a.col2; rows = a.mb2; n = a.n2; g0 = a.g_l2; g1 = a.g_b2; }
@@ -846,7 +847,7 @@ __global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTai
     }
     return;
   }
-  int b = blockIdx.x - nsg, k = 0;
+  int b = blk - nsg, k = 0;
   while (k < 2 && b >= f.blocks[k]) { b -= f.blocks[k]; ++k; }
   const int S = f.S[k], Cin = f.Cin[k], taps = f.taps[k], J = Cin * taps;
   const int total = f.Cout[k] * J;
@@ -857,6 +858,14 @@ __global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTai
     const int co = r / Cin, ci = r - co * Cin;
     gw[t] += slab_sum(slabs, S, f.stride[k], (long)co * J + tap * Cin + ci);
   }
+}
+
+__global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTailArgs f) { step_tail_body(a, f, blockIdx.x); }
+// The step tail and the step's ActNorm / invconv backward (chanmix) both only wait for the last GEMM launch and do not
+// depend on each other: one launch, the first n_tail workgroups run the tail, the rest the channel mix.
+__global__ void __launch_bounds__(256) tail_chanmix_kernel(SmallGradArgs a, StepTailArgs f, int n_tail, ChanMixArgs m) {
+  if ((int)blockIdx.x < n_tail) step_tail_body(a, f, blockIdx.x);
+  else chanmix_body(m, blockIdx.x - n_tail, gridDim.x - n_tail);
 }
 
 // ==========================================================================================
@@ -1020,6 +1029,31 @@ int launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
   return NFK_OK;
 }
 
+static int tail_blocks(const SmallGradArgs& a, StepTailArgs& f) {
+  int n = a.n1 > a.n2 ? a.n1 : a.n2;
+  if (a.n3 > n) n = a.n3;
+  f.sg_blocks = ceil_div(n > 0 ? n : 1, 32);
+  int total = f.sg_blocks * 3;
+  for (int k = 0; k < 3; ++k) {
+    const long e = (long)f.Cout[k] * f.Cin[k] * f.taps[k];
+    int b = f.S[k] > 0 ? (int)((e + 255) / 256) : 0;
+    if (b > 1024) b = 1024;
+    f.blocks[k] = b;
+    total += b;
+  }
+  return total;
+}
+int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, hipStream_t st) {
+  const int C = m.C, Cp = (C + 3) & ~3, TP = cm_tile_pixels(C);
+  const size_t lds = (size_t)(C * Cp + 2 * TP * (C + 1) + (m.part ? C * C + C : 0)) * sizeof(float);
+  if (lds > 64 * 1024 || m.M <= 0) return NFK_ERR_ARG;
+  int cb = ceil_div(m.M, TP);
+  if (m.part && cb > CM_MAX_BLOCKS) cb = CM_MAX_BLOCKS;
+  const int nt = tail_blocks(a, f);
+  hipLaunchKernelGGL(tail_chanmix_kernel, dim3(nt + cb), dim3(256), lds, st, a, f, nt, m);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
 int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st) {
   int n = a.n1 > a.n2 ? a.n1 : a.n2;
   if (a.n3 > n) n = a.n3;

@@ -181,5 +181,7 @@ struct StepTailArgs {
   int blocks[3], sg_blocks;   // filled by the launcher
 };
 int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st);
+// the same plus the step's chanmix backward in ONE launch (NFK_ERR_ARG: chanmix tile does not fit 64 KiB of LDS)
+int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, hipStream_t st);
 
 }  // namespace nfk
