@@ -215,7 +215,8 @@ int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zs
                          float *hsave, float *zout, float *ldpart, float *ws, void *stream);
 /* ws: nfk_step2d_fused_ws_floats(s) floats (0 for most steps).  Non-zero means the step runs "hidden split": grids that
  * would fill only 16-64 CUs give every pixel tile to 4 workgroups, each with a quarter of conv2/conv3, partial sums in
- * ws, finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows. */
+ * ws, finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows.  Passing ws == NULL
+ * declines the split (the step then runs on its 16-64 workgroups). */
 size_t nfk_step2d_fused_ws_floats(const nfk_step2d *s);
 int nfk_ld_finish(const float *ld_in, const float *ldpart, int nsteps, int B, int tiles, float *ld_out, void *stream);
 /* Split2d.forward / reverse / backward */

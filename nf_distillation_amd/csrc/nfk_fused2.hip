@@ -643,10 +643,10 @@ int fused2_launch(const FusedCall& c, hipStream_t st) {
   a.c = c;
   const F2Geom g = f2_geom(c.s, a.R, a.TS, a.halo);
   const int grid = a.TS == 1 ? c.s.B * (c.s.H / a.R) : (c.s.B + a.TS - 1) / a.TS;
-  if (f2_splits(c.s, a, g) == 1)
+  if (f2_splits(c.s, a, g) == 1 || !c.ws)   // ws == NULL: the caller does not want the hidden split
     return g.MT32 == 2 ? f2_dispatch<2, 1>(a, g, grid, st) : f2_dispatch<3, 1>(a, g, grid, st);
   // hidden split: the step's mixed z must be kept (the coupling tail reads it), and the tail is a second launch
-  if (!c.ws || !c.zsave) return NFK_ERR_ARG;
+  if (!c.zsave) return NFK_ERR_ARG;
   { const int rc = f2_dispatch<2, 4>(a, g, grid, st); if (rc != NFK_OK) return rc; }
   const nfk_step2d& s = c.s;
   CouplingArgs cp{};

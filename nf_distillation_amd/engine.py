@@ -54,6 +54,9 @@ class FlowEngine:
         self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
         self.first_layer_hook = None  # callable(): first layer enqueued (input x may now be reused)
         self.fused = True      # bf16 mode: one fused launch per FlowStep forward where the geometry allows
+        # hidden split of the fused step on small grids also for passes that keep nothing (a frozen teacher): on the
+        # critical path it shortens the step; beside another chain (pipeline.py) it only takes CUs away from that chain
+        self.fused_split_inference = True
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -529,7 +532,7 @@ class _EncodeFn(torch.autograd.Function):
                     saved.append((cur, zb, h1, h2, hs, arena))
                 else:
                     saved.append(None)
-                nws = lib.nfk_step2d_fused_ws_floats(C.byref(r.cs))
+                nws = lib.nfk_step2d_fused_ws_floats(C.byref(r.cs)) if (need or eng.fused_split_inference) else 0
                 ws = None
                 if nws:   # hidden-split step: partial conv3 slabs + (always) the mixed z for the coupling launch
                     if zb is None:
