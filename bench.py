@@ -218,6 +218,8 @@ def main():
         # HIP events bracket each launch: eager steps (outside the captured graph), on ONE stream, so that a launch's
         # duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r01_d_*)
         step.enable_concurrency(False)
+        if pipelined:   # the frozen teacher runs its deep-level fused steps with the pipelined schedule's 2-way split
+            teacher.flow.engine().fused_split_inference = runner.teacher_split
         run(2, eager=True)
         capi.profile_begin()
         run(args.steps, eager=True)
@@ -238,7 +240,7 @@ def main():
         # not hold this kernel
         traffic, traffic_src = None, None
         sym = {"<*,1,*>": "nfk::fused2_step_fwd_kernel<3, 1, 4, 1>", "<*,2,*>": "nfk::fused2_step_fwd_kernel<2, 2, 8, 4>",
-               "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>"}
+               "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>"}   # levels 2 / 3: the student's instances
         pmc_file = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_bf16.json")
         if args.dtype == "bf16" and os.path.exists(pmc_file):
             kern = json.load(open(pmc_file)).get("kernels", {})

@@ -218,6 +218,8 @@ int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zs
  * ws, finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows.  Passing ws == NULL
  * declines the split (the step then runs on its 16-64 workgroups). */
 size_t nfk_step2d_fused_ws_floats(const nfk_step2d *s);
+/* hidden split of the following fused launches: 4 (default), 2, or 0 = none (host-side launch parameter) */
+void nfk_fused_set_split(int ways);
 int nfk_ld_finish(const float *ld_in, const float *ldpart, int nsteps, int B, int tiles, float *ld_out, void *stream);
 /* Split2d.forward / reverse / backward */
 int nfk_split2d_fwd(const nfk_split2d *s, const float *x, const float *ld_in, float *z1out, float *hsave,

@@ -129,6 +129,7 @@ _PROTOS = {
     "nfk_step2d_fused_tiles": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_set_stamps": (None, [vp]),
     "nfk_fused_set_debug": (None, [i32]),
+    "nfk_fused_set_split": (None, [i32]),
     "nfk_step2d_fwd_fused": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_step2d_fused_ws_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_ld_finish": (i32, [vp, vp, i32, i32, i32, vp, vp]),
@@ -172,8 +173,8 @@ def lib():
 PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
                 "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>",
                 "fused2_step_fwd_kernel<*,1,*> (FlowStep forward, Cout <= 16: CIFAR level 1 = <3,1,4,1>)",
-                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8,4>)",
-                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <2,3,16,4>)",
+                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8,NS>)",
+                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <2,3,16,NS>)",
                 ) + tuple(f"dual_dgrad_wgrad_bf16_kernel {conv}, {lvl}"
                           for conv in ("conv3 (block.4: wide dgrad + narrow wgrad)", "conv2 (block.2: 512x512)",
                                        "conv1 (block.0: narrow dgrad + wide wgrad)")

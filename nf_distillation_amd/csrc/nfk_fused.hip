@@ -534,9 +534,10 @@ using namespace nfk;
 extern "C" {
 
 void nfk_fused_set_stamps(void* buf) { g_stamps = reinterpret_cast<unsigned long long*>(buf); }
+void nfk_fused_set_split(int ways) { fused2_set_split(ways >= 4 ? 1 : (ways >= 2 ? 2 : 0)); }
 void nfk_fused_set_debug(int bits) {
   g_dbg = bits & 0xff; g_force_fused = (bits >> 8) & 1; g_no_v2 = (bits >> 9) & 1;
-  fused2_set_split(((bits >> 10) & 1) ? 0 : 1);   // bit 10: no hidden split
+  fused2_set_split(((bits >> 10) & 1) ? 0 : (((bits >> 11) & 1) ? 2 : 1));   // bit 10: no hidden split, bit 11: 2-way instead of 4-way
 }
 
 static int v2_tiles(const nfk_step2d& s) {

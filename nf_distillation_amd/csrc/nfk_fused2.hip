@@ -616,7 +616,8 @@ static int f2_dispatch(const F2Args& a, const F2Geom& g, int grid, hipStream_t s
 // hidden split for tiles that need no halo (whole images per workgroup) when the grid would leave most CUs idle
 static int f2_splits(const nfk_step2d& s, const F2Args& a, const F2Geom& g) {
   const int grid = a.TS == 1 ? s.B * (s.H / a.R) : (s.B + a.TS - 1) / a.TS;
-  return (g_f2_split && g.MT32 == 2 && grid < 128) ? 4 : 1;
+  if (!(g_f2_split && g.MT32 == 2 && grid < 128)) return 1;
+  return (g_f2_split == 2) ? 2 : 4;
 }
 
 int fused2_tiles(const nfk_step2d& s) {
@@ -633,7 +634,7 @@ size_t fused2_ws_floats(const nfk_step2d& s) {
   if (!f2_pick(s, &a)) return 0;
   const F2Geom g = f2_geom(s, a.R, a.TS, a.halo);
   const int ns = f2_splits(s, a, g);
-  return ns > 1 ? (size_t)ns * s.B * s.H * s.W * s.Cout : 0;
+  return ns > 1 ? (size_t)4 * s.B * s.H * s.W * s.Cout : 0;   // sized for the widest split
 }
 void fused2_set_split(int on) { g_f2_split = on; }
 
@@ -647,10 +648,11 @@ int fused2_launch(const FusedCall& c, hipStream_t st) {
     return g.MT32 == 2 ? f2_dispatch<2, 1>(a, g, grid, st) : f2_dispatch<3, 1>(a, g, grid, st);
   // hidden split: the step's mixed z must be kept (the coupling tail reads it), and the tail is a second launch
   if (!c.zsave) return NFK_ERR_ARG;
-  { const int rc = f2_dispatch<2, 4>(a, g, grid, st); if (rc != NFK_OK) return rc; }
+  const int ns = f2_splits(c.s, a, g);
+  { const int rc = ns == 2 ? f2_dispatch<2, 2>(a, g, grid, st) : f2_dispatch<2, 4>(a, g, grid, st); if (rc != NFK_OK) return rc; }
   const nfk_step2d& s = c.s;
   CouplingArgs cp{};
-  cp.a3 = c.ws; cp.S = 4; cp.slab_stride = (long)s.B * s.H * s.W * s.Cout;
+  cp.a3 = c.ws; cp.S = ns; cp.slab_stride = (long)s.B * s.H * s.W * s.Cout;
   cp.bias3 = s.bias3; cp.es3 = s.es3; cp.z = c.zsave; cp.ldz = s.C; cp.zout = c.zout; cp.ldo = s.C; cp.hsave = c.hsave;
   cp.ld_in = nullptr; cp.dld = s.dld; cp.ld_out = c.ldpart;   // one log-det slot per sample (tiles == 1 here)
   cp.HW = s.H * s.W; cp.C = s.C; cp.Cout = s.Cout; cp.additive = s.additive; cp.has_ld = 1;

@@ -56,7 +56,7 @@ class FlowEngine:
         self.fused = True      # bf16 mode: one fused launch per FlowStep forward where the geometry allows
         # hidden split of the fused step on small grids also for passes that keep nothing (a frozen teacher): on the
         # critical path it shortens the step; beside another chain (pipeline.py) it only takes CUs away from that chain
-        self.fused_split_inference = True
+        self.fused_split_inference = 4   # ways: 4, 2, 0 (none) or "frugal" (see _EncodeFn.forward)
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -532,7 +532,12 @@ class _EncodeFn(torch.autograd.Function):
                     saved.append((cur, zb, h1, h2, hs, arena))
                 else:
                     saved.append(None)
-                nws = lib.nfk_step2d_fused_ws_floats(C.byref(r.cs)) if (need or eng.fused_split_inference) else 0
+                # hidden split of this launch: 4-way when a backward follows (critical path), else the engine's policy
+                ways = 4 if need else eng.fused_split_inference
+                if ways == "frugal":   # beside another chain: only the grids that would fill fewer than 32 CUs
+                    ways = 4 if (B * r.H * r.W + 63) // 64 < 32 else 0
+                lib.nfk_fused_set_split(int(ways))   # host-side launch parameter
+                nws = lib.nfk_step2d_fused_ws_floats(C.byref(r.cs)) if ways else 0
                 ws = None
                 if nws:   # hidden-split step: partial conv3 slabs + (always) the mixed z for the coupling launch
                     if zb is None:
