@@ -863,9 +863,11 @@ __device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const Ste
 __global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTailArgs f) { step_tail_body(a, f, blockIdx.x); }
 // The step tail and the step's ActNorm / invconv backward (chanmix) both only wait for the last GEMM launch and do not
 // depend on each other: one launch, the first n_tail workgroups run the tail, the rest the channel mix.
-__global__ void __launch_bounds__(256) tail_chanmix_kernel(SmallGradArgs a, StepTailArgs f, int n_tail, ChanMixArgs m) {
-  if ((int)blockIdx.x < n_tail) step_tail_body(a, f, blockIdx.x);
-  else chanmix_body(m, blockIdx.x - n_tail, gridDim.x - n_tail);
+// The channel-mix workgroups come first in the grid: they are few and each is a chain of dependent loads, so they should
+// not queue behind the (many, short) slab-reduction workgroups.
+__global__ void __launch_bounds__(256) tail_chanmix_kernel(SmallGradArgs a, StepTailArgs f, int n_cm, ChanMixArgs m) {
+  if ((int)blockIdx.x < n_cm) chanmix_body(m, blockIdx.x, n_cm);
+  else step_tail_body(a, f, blockIdx.x - n_cm);
 }
 
 // ==========================================================================================
@@ -1050,7 +1052,7 @@ int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArg
   int cb = ceil_div(m.M, TP);
   if (m.part && cb > CM_MAX_BLOCKS) cb = CM_MAX_BLOCKS;
   const int nt = tail_blocks(a, f);
-  hipLaunchKernelGGL(tail_chanmix_kernel, dim3(nt + cb), dim3(256), lds, st, a, f, nt, m);
+  hipLaunchKernelGGL(tail_chanmix_kernel, dim3(cb + nt), dim3(256), lds, st, a, f, cb, m);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
