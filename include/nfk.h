@@ -194,6 +194,26 @@ int nfk_step2d_bwd_deferred(const nfk_step2d *s, const nfk_step2d_grads *g, cons
                             const float *h1, const float *h2, const float *hsave, const float *g_out,
                             const float *g_ext, const float *g_ld, float *g_x, float *ws, float *ga, float *wslab,
                             void *stream);
+/* Chained form for a run of FlowSteps of one level walked in backward order (models/flows.py:178-186 reversed by
+ * autograd).  A step's backward ends in the channel-mix launch that produces g_x -- which is the output gradient of the
+ * step that comes next in backward order -- so that launch can also run the NEXT step's coupling-tail backward
+ * (models/layers.py:377-392 differentiated) on the pixel tile it holds, and the next call starts at its first GEMM.
+ *   next          (optional) describes the step the following call will process: its descriptor, saved z / hsave, its
+ *                 external output gradient (hint grads; NULL if none) and the ws / ga buffers THAT call will receive,
+ *                 which must differ from this call's (two workspaces used alternately).
+ *   coupling_rows 0: this call runs its own coupling backward (as nfk_step2d_bwd); > 0: the previous call already did,
+ *                 passing this step as `next`, and left that many partial rows (the value it returned in *next_rows).
+ * Same B, H, W, C for both steps.  ga / wslab as in nfk_step2d_bwd_deferred (NULL, NULL = nfk_step2d_bwd). */
+typedef struct nfk_step2d_next {
+  const nfk_step2d *s;
+  const float *z, *hsave;   /* saved by that step's forward */
+  const float *g_ext;       /* [M][C] or NULL */
+  float *ws, *ga;           /* what the following call passes as ws / ga (ga NULL outside deferred mode) */
+} nfk_step2d_next;
+int nfk_step2d_bwd_chain(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
+                         const float *h1, const float *h2, const float *hsave, const float *g_out, const float *g_ext,
+                         const float *g_ld, float *g_x, float *ws, float *ga, float *wslab, int coupling_rows,
+                         const nfk_step2d_next *next, int *next_rows, void *stream);
 size_t nfk_step2d_bwd_ga_floats(const nfk_step2d *s);
 size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d *s);
 int nfk_aux_join(void *stream);

@@ -55,6 +55,10 @@ class Step2dGrads(C.Structure):
                 ("g_l2", c_fp), ("g_w3", c_fp), ("g_bias3", c_fp), ("g_l3", c_fp), ("mix_part", c_fp)]
 
 
+class Step2dNext(C.Structure):
+    _fields_ = [("s", C.POINTER(Step2d)), ("z", c_fp), ("hsave", c_fp), ("g_ext", c_fp), ("ws", c_fp), ("ga", c_fp)]
+
+
 class Split2d(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("bias", c_fp), ("es", c_fp), ("wt", c_fp), ("wd", c_fp)]
@@ -121,6 +125,8 @@ _PROTOS = {
                              vp, vp]),
     "nfk_step2d_bwd_deferred": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp, vp, vp]),
+    "nfk_step2d_bwd_chain": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp,
+                                   vp, vp, vp, vp, i32, C.POINTER(Step2dNext), C.POINTER(i32), vp]),
     "nfk_step2d_bwd_ga_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_bwd_wslab_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_aux_join": (i32, [vp]),

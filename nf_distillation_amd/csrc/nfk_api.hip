@@ -38,7 +38,8 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   w.d1slab = o; o += align4((size_t)w.S1 * M * Ch);
   w.col2 = o; o += align4((size_t)w.mb2 * 2 * hid);
   w.col1 = o; o += align4((size_t)w.mb1 * 2 * hid);
-  w.tail = o; o += align4((size_t)s->B * 2 * s->Cout);
+  // coupling-tail partial rows: one per sample, or one per channel-mix workgroup of the previous step (chained backward)
+  w.tail = o; o += align4((size_t)(s->B > 256 ? s->B : 256) * 2 * s->Cout);
   // the three weight gradients' split slabs, each in a region of its own (reduced together by step_tail_kernel)
   w.ws3 = align4((size_t)w.S3w * s->Cout * 9 * hid);
   w.ws2 = align4((size_t)w.S2w * hid * hid);
@@ -248,7 +249,8 @@ int nfk_step2d_inv(const nfk_step2d* s, const float* y, int ldy, const float* ld
 static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
                            const float* h1, const float* h2, const float* hsave, const float* g_out,
                            const float* g_ext, const float* g_ld, float* g_x, float* ws, float* ga, float* wslab_ext,
-                           void* stream) {
+                           void* stream, int coupling_rows = 0, const nfk_step2d_next* next = nullptr,
+                           int* next_rows = nullptr) {
   hipStream_t st = S_(stream);
   const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, hid = s->hidden, Cout = s->Cout;
   const int M = B * H * W, HW = H * W, bf = s->bf16;
@@ -267,7 +269,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   cb.gout = g_out; cb.ldg = C; cb.gext = g_ext; cb.ldge = C; cb.gld = g_ld; cb.z = z; cb.ldz = C; cb.h = hsave;
   cb.es3 = s->es3; cb.ga3 = ga3; cb.gz = gz; cb.ldgz = C; cb.part = tail; cb.HW = HW; cb.C = C; cb.Cout = Cout;
   cb.additive = s->additive;
-  NFK_TRY(launch_coupling_bwd(cb, B, st));
+  if (coupling_rows <= 0) NFK_TRY(launch_coupling_bwd(cb, B, st));   // else: done by the previous call of the chain
   // Each conv's weight gradient (slabs -> finalize) and dgrad read the same output gradient and are independent.
   // bf16 "dual" mode runs the two GEMMs as ONE launch on the caller's stream; otherwise the weight gradient goes to
   // the auxiliary stream (if one is set), forked here and joined at the end of the call / by nfk_aux_join.
@@ -321,7 +323,8 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
 
   nfk_small_grad_args sg{};
-  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb1; sg.mb2 = L.mb2; sg.B = B;
+  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb1; sg.mb2 = L.mb2;
+  sg.B = coupling_rows > 0 ? coupling_rows : B;
   sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
   sg.g_l3 = g->g_l3;
@@ -335,8 +338,23 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = S1_used; m.slab_stride = (long)M * Ch;
   m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
   // dual mode: the step tail (slab reductions + per-channel gradients) and this channel mix share one launch
+  if (next_rows) *next_rows = 0;
+  CouplingBwdArgs nb{};
+  bool chained = false;
+  if (next && next->s && have_tail) {
+    const nfk_step2d* n = next->s;
+    if (!next_rows || n->B != B || n->H != H || n->W != W || n->C != C || !next->ws || next->ws == ws || (deferred && next->ga == ga))
+      return NFK_ERR_ARG;
+    const StepBwdWs Ln = step_bwd_layout(n);
+    nb.gext = next->g_ext; nb.ldge = C; nb.gld = g_ld; nb.z = next->z; nb.ldz = C; nb.h = next->hsave;
+    nb.es3 = n->es3; nb.ga3 = (deferred && next->ga) ? next->ga : next->ws + Ln.ga3; nb.gz = next->ws + Ln.gz;
+    nb.ldgz = C; nb.part = next->ws + Ln.tail; nb.HW = HW; nb.C = C; nb.Cout = n->Cout; nb.additive = n->additive;
+    chained = true;
+  }
   if (have_tail) {
-    const int rc = launch_tail_chanmix(sg, tail_f, m, st);
+    int rc = launch_tail_chanmix(sg, tail_f, m, chained ? &nb : nullptr, st);
+    if (rc == NFK_OK && chained && next_rows) *next_rows = chanmix_parts(M, C);
+    if (rc == NFK_ERR_ARG && chained) rc = launch_tail_chanmix(sg, tail_f, m, nullptr, st);   // does not fit: unchained
     if (rc == NFK_ERR_ARG) { NFK_TRY(launch_step_tail(sg, tail_f, st)); NFK_TRY(launch_chanmix(m, st)); }
     else if (rc != NFK_OK) return rc;
   } else {
@@ -361,6 +379,13 @@ int nfk_step2d_bwd_deferred(const nfk_step2d* s, const nfk_step2d_grads* g, cons
                             const float* g_ext, const float* g_ld, float* g_x, float* ws, float* ga, float* wslab,
                             void* stream) {
   return step2d_bwd_impl(s, g, x, ldx, z, h1, h2, hsave, g_out, g_ext, g_ld, g_x, ws, ga, wslab, stream);
+}
+int nfk_step2d_bwd_chain(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
+                         const float* h1, const float* h2, const float* hsave, const float* g_out, const float* g_ext,
+                         const float* g_ld, float* g_x, float* ws, float* ga, float* wslab, int coupling_rows,
+                         const nfk_step2d_next* next, int* next_rows, void* stream) {
+  return step2d_bwd_impl(s, g, x, ldx, z, h1, h2, hsave, g_out, g_ext, g_ld, g_x, ws, ga, wslab, stream, coupling_rows,
+                         next, next_rows);
 }
 size_t nfk_step2d_bwd_ga_floats(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;

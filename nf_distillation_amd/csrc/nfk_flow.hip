@@ -396,7 +396,12 @@ static inline __host__ __device__ int cm_tile_pixels(int C) {
   return tp;
 }
 
-__device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx, const int nblk) {
+// `nx` (optional, nx.ga3 != null): the coupling backward of the step that FOLLOWS in backward order, whose output gradient
+// is exactly the g_x this launch produces -- done here per pixel tile instead of in a launch of its own (the tail /
+// channel-mix launch of a step is followed by nothing else).  Its per-column sums become one partial row per
+// workgroup (instead of one per sample), reduced by the same small-gradient code later.
+__device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx, const int nblk,
+                                             const CouplingBwdArgs* nx = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C, Cp = (C + 3) & ~3, XS = C + 1, G4 = Cp / 4;
   const int TP = cm_tile_pixels(C);
@@ -405,6 +410,13 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
   float* Gl = Xl + TP * XS;         // [TP][C+1] (backward: x_in tile)
   float* Pl = Gl + TP * XS;         // [C*C + C] (backward: partial sums, each element owned by one thread)
   const int E = C * C + C;
+  const bool fuse = nx != nullptr && nx->ga3 != nullptr;
+  const int Chn = C / 2, C2n = C - Chn, Gn = 256 / (C2n > 0 ? C2n : 1);
+  float* Ol = Pl + (a.part ? E : 0);      // [TP][C+1] this launch's g_x tile      (fused coupling only)
+  float* Al = Ol + TP * XS;               // [Gn][4][C2] per-group column sums     (fused coupling only)
+  float* Pc = Al + Gn * 4 * C2n;          // [4][C2] running column sums of this workgroup
+  if (fuse)
+    for (int idx = threadIdx.x; idx < 4 * C2n; idx += blockDim.x) Pc[idx] = 0.f;
   for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
     const int r = idx / C, q = idx - r * C;  // Wm[r][q]
     if (a.trans) Wl[r * Cp + q] = a.Wm[idx];      // in = r (rows of Wm), out = q
@@ -453,6 +465,9 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (o + r < C) zp[r] = acc[r];
       }
+      if (fuse)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < C) Ol[p * XS + o + r] = acc[r];
     }
     if (a.part) {
       for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
@@ -467,10 +482,65 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
         Pl[idx] += s;
       }
     }
+    if (fuse) {
+      // coupling backward of the next step on this tile (same arithmetic as coupling_bwd_kernel)
+      __syncthreads();
+      const CouplingBwdArgs& n = *nx;
+      const int j = threadIdx.x % C2n, g = threadIdx.x / C2n;
+      float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
+      if (g < Gn) {
+        for (int pp = g; pp < TP; pp += Gn) {
+          const long m = (long)m0 + pp;
+          if (m >= a.M) break;
+          float g2 = Ol[pp * XS + Chn + j];
+          if (n.gext) g2 += n.gext[m * n.ldge + Chn + j];
+          if (n.additive) {
+            const float h = n.h[m * n.Cout + j];
+            n.gz[m * n.ldgz + Chn + j] = g2;
+            const float ga = g2 * n.es3[j];
+            n.ga3[m * n.Cout + j] = ga;
+            sb0 += ga; sl0 += g2 * h;
+          } else {
+            const float gl = n.gld ? n.gld[m / n.HW] : 0.f;
+            const float shf = n.h[m * n.Cout + 2 * j], sr = n.h[m * n.Cout + 2 * j + 1];
+            const float sc = sigmoidf(sr + 2.f);
+            const float z2 = n.z[m * n.ldz + Chn + j];
+            const float gshift = g2 * sc;
+            const float gsr = g2 * (z2 + shf) * sc * (1.f - sc) + gl * (1.f - sc);
+            n.gz[m * n.ldgz + Chn + j] = gshift;
+            const float ga0 = gshift * n.es3[2 * j], ga1 = gsr * n.es3[2 * j + 1];
+            n.ga3[m * n.Cout + 2 * j] = ga0;
+            n.ga3[m * n.Cout + 2 * j + 1] = ga1;
+            sb0 += ga0; sl0 += gshift * shf; sb1 += ga1; sl1 += gsr * sr;
+          }
+        }
+        float* row = Al + (long)g * 4 * C2n;
+        row[j] = sb0; row[C2n + j] = sl0; row[2 * C2n + j] = sb1; row[3 * C2n + j] = sl1;
+      }
+      __syncthreads();
+      for (int jj = threadIdx.x; jj < 4 * C2n; jj += blockDim.x) {
+        float t = 0.f;
+        for (int gg = 0; gg < Gn; ++gg) t += Al[(long)gg * 4 * C2n + jj];
+        Pc[jj] += t;
+      }
+    }
   }
   if (a.part) {
     float* part = a.part + (long)bx * E;
     for (int idx = threadIdx.x; idx < E; idx += blockDim.x) part[idx] = Pl[idx];
+  }
+  if (fuse) {
+    __syncthreads();
+    const CouplingBwdArgs& n = *nx;
+    float* part = n.part + (long)bx * 2 * n.Cout;   // one partial row per workgroup
+    for (int jj = threadIdx.x; jj < C2n; jj += blockDim.x) {
+      const float t0 = Pc[jj], t1 = Pc[C2n + jj], t2 = Pc[2 * C2n + jj], t3 = Pc[3 * C2n + jj];
+      if (n.additive) { part[jj] = t0; part[n.Cout + jj] = 3.f * t1; }
+      else {
+        part[2 * jj] = t0; part[2 * jj + 1] = t2;
+        part[n.Cout + 2 * jj] = 3.f * t1; part[n.Cout + 2 * jj + 1] = 3.f * t3;
+      }
+    }
   }
 }
 __global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) { chanmix_body(a, blockIdx.x, gridDim.x); }
@@ -865,8 +935,9 @@ __global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTai
 // depend on each other: one launch, the first n_tail workgroups run the tail, the rest the channel mix.
 // The channel-mix workgroups come first in the grid: they are few and each is a chain of dependent loads, so they should
 // not queue behind the (many, short) slab-reduction workgroups.
-__global__ void __launch_bounds__(256) tail_chanmix_kernel(SmallGradArgs a, StepTailArgs f, int n_cm, ChanMixArgs m) {
-  if ((int)blockIdx.x < n_cm) chanmix_body(m, blockIdx.x, n_cm);
+__global__ void __launch_bounds__(256) tail_chanmix_kernel(SmallGradArgs a, StepTailArgs f, int n_cm, ChanMixArgs m,
+                                                           CouplingBwdArgs nx) {
+  if ((int)blockIdx.x < n_cm) chanmix_body(m, blockIdx.x, n_cm, &nx);
   else step_tail_body(a, f, blockIdx.x - n_cm);
 }
 
@@ -1045,14 +1116,21 @@ static int tail_blocks(const SmallGradArgs& a, StepTailArgs& f) {
   }
   return total;
 }
-int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, hipStream_t st) {
-  const int C = m.C, Cp = (C + 3) & ~3, TP = cm_tile_pixels(C);
-  const size_t lds = (size_t)(C * Cp + 2 * TP * (C + 1) + (m.part ? C * C + C : 0)) * sizeof(float);
+int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, const CouplingBwdArgs* next,
+                        hipStream_t st) {
+  const int C = m.C, Cp = (C + 3) & ~3, TP = cm_tile_pixels(C), C2 = C - C / 2;
+  size_t lds = (size_t)(C * Cp + 2 * TP * (C + 1) + (m.part ? C * C + C : 0)) * sizeof(float);
+  CouplingBwdArgs nx{};
+  if (next) {
+    if (C2 < 1 || C2 > 256) return NFK_ERR_ARG;
+    nx = *next;
+    lds += (size_t)(TP * (C + 1) + (256 / C2) * 4 * C2 + 4 * C2) * sizeof(float);
+  }
   if (lds > 64 * 1024 || m.M <= 0) return NFK_ERR_ARG;
   int cb = ceil_div(m.M, TP);
   if (m.part && cb > CM_MAX_BLOCKS) cb = CM_MAX_BLOCKS;
   const int nt = tail_blocks(a, f);
-  hipLaunchKernelGGL(tail_chanmix_kernel, dim3(cb + nt), dim3(256), lds, st, a, f, cb, m);
+  hipLaunchKernelGGL(tail_chanmix_kernel, dim3(cb + nt), dim3(256), lds, st, a, f, cb, m, nx);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

@@ -182,6 +182,9 @@ struct StepTailArgs {
 };
 int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st);
 // the same plus the step's chanmix backward in ONE launch (NFK_ERR_ARG: chanmix tile does not fit 64 KiB of LDS)
-int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, hipStream_t st);
+// `next` (optional): coupling backward of the step that follows in backward order, fused into the channel-mix workgroups;
+// its partial rows are then one per channel-mix workgroup (chanmix_parts(M, C)), not one per sample
+int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, const CouplingBwdArgs* next,
+                        hipStream_t st);
 
 }  // namespace nfk

@@ -57,6 +57,7 @@ class FlowEngine:
         # hidden split of the fused step on small grids also for passes that keep nothing (a frozen teacher): on the
         # critical path it shortens the step; beside another chain (pipeline.py) it only takes CUs away from that chain
         self.fused_split_inference = 4   # ways: 4, 2, 0 (none) or "frugal" (see _EncodeFn.forward)
+        self.chain_backward = True       # nfk_step2d_bwd_chain (False: one independent nfk_step2d_bwd call per step)
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -675,12 +676,60 @@ class _EncodeFn(torch.autograd.Function):
             if wslab is None or wslab.numel() < wslab_max:
                 wslab = st["wslab"] = torch.empty(wslab_max, device=dev, dtype=torch.float32)
 
+        # Steps are walked as a chain (nfk_step2d_bwd_chain): the launch that ends a step's backward also runs the
+        # coupling backward of the step that follows on the same level, into that step's workspace -- hence two
+        # workspaces used alternately.
+        ws_max = max([lib.nfk_step2d_bwd_ws_floats(C.byref(r.cs)) for r in recs if r.kind == "step"] + [4])
+        ws_pair = [torch.empty(ws_max, device=dev, dtype=torch.float32) for _ in range(2)] if eng.chain_backward else None
+        order = list(zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)))
+        ext_of = {}
+
+        def _ext(i):
+            if i not in ext_of:
+                go_i = order[i][2]
+                ext_of[i] = _nhwc(go_i.to(torch.float32)) if go_i is not None else None
+            return ext_of[i]
+
         g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
-        for r, sv, go in zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)):
-            ext = _nhwc(go.to(torch.float32)) if go is not None else None
+        rows_in, n_step = 0, 0   # partial rows the previous call left for this step (0: none); steps processed
+        for i, (r, sv, go) in enumerate(order):
+            ext = _ext(i)
             if g is None and ext is None:
                 continue  # nothing flows into this layer's output
-            if r.kind == "step":
+            if r.kind == "step" and ws_pair is not None:
+                x_in, zb, h1, h2, hs, _ = sv
+                blk = r.mod.block
+                gs = Step2dGrads()
+                gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
+                gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
+                gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
+                off, nb = part_off[r.idx]
+                gs.mix_part = parts.data_ptr() + 4 * off
+                gx = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                ws = ws_pair[n_step & 1]
+                g_main, g_ext = (g, ext) if g is not None else (ext, None)
+                nxt, nxt_p = None, None
+                if i + 1 < len(order) and order[i + 1][0].kind == "step":
+                    rn, svn = order[i + 1][0], order[i + 1][1]
+                    if (rn.H, rn.W, rn.C) == (r.H, r.W, r.C):
+                        nxt = capi.Step2dNext()
+                        nxt.s = C.pointer(rn.cs)
+                        nxt.z, nxt.hsave, nxt.g_ext = ptr(svn[1]), ptr(svn[4]), ptr(_ext(i + 1))
+                        nxt.ws = ptr(ws_pair[(n_step + 1) & 1])
+                        nxt.ga = (ga_all.data_ptr() + 4 * ga_off[rn.idx]) if deferred else None
+                        nxt_p = C.byref(nxt)
+                rows_out = C.c_int32(0)
+                check(lib.nfk_step2d_bwd_chain(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
+                                               ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws),
+                                               (ga_all.data_ptr() + 4 * ga_off[r.idx]) if deferred else None,
+                                               ptr(wslab) if deferred else None, rows_in, nxt_p, C.byref(rows_out), s),
+                      "nfk_step2d_bwd_chain")
+                rows_in = rows_out.value
+                n_step += 1
+                g = gx
+                if eng.grad_hook is not None:
+                    eng.grad_hook(r.idx)
+            elif r.kind == "step":
                 x_in, zb, h1, h2, hs, _ = sv
                 blk = r.mod.block
                 gs = Step2dGrads()

@@ -127,7 +127,7 @@ def _fused_vs_unfused(name):
     assert num / (da ** 0.5 * db ** 0.5) > 0.9995
 
 
-def _grads_with(mode, halo, g, cfg, sd, x, noise):
+def _grads_with(mode, halo, g, cfg, sd, x, noise, chain=False):
     from nf_distillation_amd import capi
     lib = capi.lib()
     lib.nfk_set_bwd_mode(mode)
@@ -135,6 +135,7 @@ def _grads_with(mode, halo, g, cfg, sd, x, noise):
     lib.nfk_set_tuning(3011 if halo else 3010)   # conv3 weight gradient through the halo-tile kernel or the generic one
     try:
         model = build(cfg, sd)
+        model.flow.engine().chain_backward = chain
         outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
         bpd.mean().backward()
         torch.cuda.synchronize()
@@ -158,6 +159,27 @@ def test_dual_dgrad_wgrad_launch_is_bit_identical():
     for other in res[1:]:
         for k in res[0]:
             assert torch.equal(res[0][k], other[k]), k
+
+
+def test_chained_backward_equals_per_step_calls():
+    """nfk_step2d_bwd_chain folds the next step's coupling backward into the launch that ends the current step's.  The
+    element-wise results are the same numbers; only the per-channel sums behind block.4's bias / logs gradients are
+    reduced over pixel tiles instead of over samples.  Everything else must agree bit for bit."""
+    g = Golden("cifar_k8_full")
+    cfg = g.cfg
+    sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+    h, w, c = cfg["image_shape"]
+    x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 9)
+    a = _grads_with(2, True, g, cfg, sd, x, noise, chain=True)
+    b = _grads_with(2, True, g, cfg, sd, x, noise, chain=False)
+    n_sum = 0
+    for k in a:
+        if k.endswith("block.4.conv.bias") or k.endswith("block.4.logs"):
+            assert rel_err(a[k], b[k]) < 1e-5, (k, rel_err(a[k], b[k]))
+            n_sum += 1
+        else:
+            assert torch.equal(a[k], b[k]), k
+    assert n_sum > 0
 
 
 def test_halo_tile_kernels_agree_with_generic_gemms():
