@@ -303,9 +303,14 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) f[u] = f2_ldw(r2, voffL, soff + u * 1024);
   };
-  // the first chunk's W2 rows travel while conv1 computes
-  load_w2(nc0, 0, w2a);
-  load_w2(nc0, 1, w2b);
+  // the first chunk's W2 rows travel while conv1 computes: eight 1 KiB loads per channel tile of conv1, between its MFMAs
+  // and its epilogue (all 32 at once hold every wave at the vector-memory issue for ~2.5K cycles, the last wave longest)
+  auto load_w2_part = [&](int part) {   // part 0..3: w2a[0..7], w2a[8..15], w2b[0..7], w2b[8..15]
+    const int half = part >> 1, u0 = (part & 1) * 8;
+    const int soff = ((nc0 * 4 + swid) * (Kp2 / 16) + half * 16) * 1024;
+#pragma unroll
+    for (int u = u0; u < u0 + 8; ++u) (half ? w2b : w2a)[u] = f2_ldw(r2, voffL, soff + u * 1024);
+  };
   {
     const char* x1_lane = X1 + l32 * g.X1S + hi * 16;
     char* h1w[MT32];
@@ -345,6 +350,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
         if (!XB_REG) __builtin_amdgcn_sched_barrier(0);
       }
       if (j + W1R < 4) load_w1(j + W1R, w1[j % W1R]);
+      load_w2_part(j);
       const int n0 = (wid * 4 + j) * 32 + 4 * hi;
       // h1 write address: px*1024 + (((slot ^ px) & 15) | (slot & 48)) * 16 + 8*hi with slot = wid*16 + j*4 + gi:
       // the low 2 slot bits are gi, so (slot ^ px) & 15 = ((j*4 + gi) ^ (px & 15)); px & 15 = l32 & 15 in every tile
