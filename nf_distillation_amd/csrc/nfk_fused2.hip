@@ -8,12 +8,13 @@
 //   2. im2col   3x3 taps of z1 on the h-region (tile + 1 halo row)                          -> LDS (bf16)
 //   3. conv1    3x3 C/2->512, ActNorm, ReLU.  32x32x16 MFMA: every wave owns 4 tiles of 32 output channels and
 //               keeps their W1 rows in registers from the start of the kernel               -> h1 in LDS (bf16)
-//   4. conv2    1x1 512->512 in 4 chunks of 128 channels (32 per wave).  A fragments (W2 rows) stream from L2
-//               through a two-half register ring, one half-chunk (16 k-steps) ahead; every B fragment (32 pixels
-//               x 16 k of h1) read from LDS feeds one 32-cycle MFMA, so the LDS array runs at half its rate
-//               instead of saturated (16x16x32 tiles, generation 1)                         -> h2 chunk in LDS
-//   5. conv3    3x3 512->Cout: each h2 chunk is consumed at once as a K-slice (9 taps = shifted LDS rows); wave w
-//               takes the w-th 32 channels of the chunk for all 9 taps; reduced across waves through LDS at the end
+//   4. conv2    1x1 512->512 in ONE pass over k: every wave owns 4 tiles of 32 output channels (12 accumulator tiles
+//               of 32x32 at 96 pixels) so that a B fragment (32 pixels x 16 k of h1) read from LDS feeds four MFMAs per
+//               pixel tile.  A fragments (W2 rows) stream from L2 through a 32-fragment register ring, each slot
+//               reloaded in place 8 k-steps ahead.  h2 = ReLU(ActNorm(.)) then REPLACES h1 in the same LDS image
+//   5. conv3    3x3 512->Cout over the h2 image (9 taps = shifted LDS rows): per 128-channel chunk, wave w takes the
+//               chunk's w-th 32 channels for all 9 taps; W3 fragments sit in a register ring up to four chunks deep,
+//               requested before conv2's epilogue; the waves' sums are reduced through LDS at the end
 //   6. tail     bias, exp(3 logs), sigmoid(.+2), (z2+shift)*scale, per-tile partial sum of log-scales
 //   h1 / h2 never travel through HBM between the convolutions; when a backward will follow they are copied out
 //   once, from LDS, in whole 16-byte pieces of contiguous rows.
@@ -36,7 +37,7 @@ struct F2Args {
 
 struct F2Geom {
   int RH, RZ, P_h, MT32, K1, K1M, K1p, X1S, NT3;
-  size_t oZm, oWf, oPar, oX1, oH1, oH2c, oZero, total;
+  size_t oZm, oWf, oPar, oX1, oH1, oZero, total;
 };
 
 __host__ __device__ static inline F2Geom f2_geom(const nfk_step2d& s, int R, int TS, int halo) {
@@ -60,8 +61,8 @@ __host__ __device__ static inline F2Geom f2_geom(const nfk_step2d& s, int R, int
   g.oX1 = o; o += (size_t)g.MT32 * 32 * g.X1S;
   o = (o + 15) & ~size_t(15);
   g.oH1 = o; o += (size_t)g.MT32 * 32 * 1024;
-  g.oH2c = o; o += (size_t)g.MT32 * 32 * 256;
-  g.oZero = o; o += 16;   // sixteen zero bytes: conv3's zero padding reads them instead of masking fragments
+  g.oZero = o; o += 3 * 256 + 16;   // sixteen zero bytes per 128-channel chunk, 256 bytes apart (the chunks' pitch in
+                                    // the h2 image): conv3's zero padding reads them instead of masking fragments
   g.total = o;
   return g;
 }
@@ -94,8 +95,6 @@ __device__ __forceinline__ bf16x8f f2_ldw(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ int f2_h1_off(int px, int slot) {
   return px * 1024 + ((((slot ^ px) & 15) | (slot & ~15)) << 4);
 }
-// h2 chunk image: 256-byte rows (128 channels = 16 slots), slot ^ (px & 15)
-__device__ __forceinline__ int f2_h2_off(int px, int slot) { return px * 256 + (((slot ^ px) & 15) << 4); }
 
 // NS > 1 ("hidden split", for grids that would fill only 64 or 16 CUs): NS workgroups share a pixel tile; each runs
 // the whole mix / im2col / conv1 but only its 4/NS chunks of conv2 + conv3, and leaves its partial conv3 sums in slab
@@ -114,15 +113,12 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   float* Wl = reinterpret_cast<float*>(smem_f2 + g.oWf);
   char* X1 = smem_f2 + g.oX1;
   char* H1 = smem_f2 + g.oH1;
-  char* H2c = smem_f2 + g.oH2c;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l32 = lane & 31, hi = lane >> 5;      // 32x32x16 operand roles: row / k-half
   const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 operand roles (conv3)
 
   const int tps = (TS == 1) ? H / R : 1;
   const int wg = (NS == 1) ? (int)blockIdx.x : (int)blockIdx.x / NS, qs = (NS == 1) ? 0 : (int)blockIdx.x % NS;
-  constexpr int NCH = 4 / NS;   // conv2 chunks (of 128 channels) per workgroup
-  const int nc0 = qs * NCH;
   const int b0 = (TS == 1) ? wg / tps : wg * TS;
   const int tile = (TS == 1) ? wg - b0 * tps : 0;
   const int row0 = tile * R;
@@ -203,7 +199,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       Pb2[idx] = preg[i][2] * preg[i][3]; Pe2[idx] = preg[i][3];
     }
     if (tid < Cout) { Pb3[tid] = b3r; Pe3[tid] = e3r; }
-    if (tid < 4) reinterpret_cast<unsigned*>(smem_f2 + g.oZero)[tid] = 0u;
+    if (tid < 16) reinterpret_cast<unsigned*>(smem_f2 + g.oZero + (tid >> 2) * 256)[tid & 3] = 0u;
   }
   // conv1's weight fragments travel during the mix and the im2col
 #pragma unroll
@@ -278,8 +274,9 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     const int y = row0 + rr - halo, b = b0 + sm;
     hmask[mt] = (ph < g.P_h && (unsigned)y < (unsigned)H && b < s.B) ? 0xFFFFFFFFu : 0u;
   }
-  // coalesced copy of the 64 output pixels' rows of an LDS image to a global [M][512] bf16 array (16-byte pieces)
-  auto save_rows = [&](__bf16* dstg, int col0, const char* img, int slots_log2, bool is_h1) {
+  // coalesced copy of the 64 output pixels' rows (16-byte slots slot0 .. slot0 + 2^slots_log2 - 1) of the LDS image to
+  // columns col0.. of a global [M][512] bf16 array
+  auto save_rows = [&](__bf16* dstg, int col0, const char* img, int slots_log2, int slot0) {
     const int spr = 1 << slots_log2;                 // 16-byte slots per row
     const int slot = tid & (spr - 1);
     for (int po = tid >> slots_log2; po < 64; po += (256 >> slots_log2)) {
@@ -288,28 +285,30 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       if (b >= s.B) continue;
       const int ph = sm * g.RH * W + (rr + halo) * W + xx;
       const long m = (long)b * HW + (row0 + rr) * W + xx;
-      const u32x4f v = *reinterpret_cast<const u32x4f*>(img + (is_h1 ? f2_h1_off(ph, slot) : f2_h2_off(ph, slot)));
+      const u32x4f v = *reinterpret_cast<const u32x4f*>(img + f2_h1_off(ph, slot0 + slot));
       *reinterpret_cast<u32x4f*>(dstg + m * HID + col0 + slot * 8) = v;
     }
   };
 
   // ------------------------------------------------------------------ 3. conv1 -> H1
   constexpr int Kp2 = HID, Kp3 = 9 * HID;    // both multiples of 64: no row padding
-  bf16x8f w2a[16], w2b[16];
+  constexpr int NCH = 4 / NS;                // channel tiles (32 channels) of conv2 per wave: tiles (nc0 + i) * 4 + wid
+  constexpr int RD = 32 / NCH;               // W2 register ring: RD k-steps x NCH tiles = 32 fragments (128 VGPRs)
+  const int nc0 = qs * NCH;
+  bf16x8f w2r[RD][NCH];
   const __amdgpu_buffer_rsrc_t r2 = f2_rsrc(s.wf2, (unsigned)HID * Kp2 * 2);
   const __amdgpu_buffer_rsrc_t r3 = f2_rsrc(s.wf3, (unsigned)NT3 * 16 * Kp3 * 2);
-  auto load_w2 = [&](int nc, int half, bf16x8f (&f)[16]) {   // row tile nc*4 + swid, k-steps half*16 ..
-    const int soff = ((nc * 4 + swid) * (Kp2 / 16) + half * 16) * 1024;
+  int w2s[NCH];   // scalar byte offset of k-step 0 of each of this wave's channel tiles
 #pragma unroll
-    for (int u = 0; u < 16; ++u) f[u] = f2_ldw(r2, voffL, soff + u * 1024);
-  };
-  // the first chunk's W2 rows travel while conv1 computes: eight 1 KiB loads per channel tile of conv1, between its MFMAs
+  for (int i = 0; i < NCH; ++i) w2s[i] = ((nc0 + i) * 4 + swid) * (Kp2 / 16) * 1024;
+  // the ring's first fill travels while conv1 computes: eight 1 KiB loads per channel tile of conv1, between its MFMAs
   // and its epilogue (all 32 at once hold every wave at the vector-memory issue for ~2.5K cycles, the last wave longest)
-  auto load_w2_part = [&](int part) {   // part 0..3: w2a[0..7], w2a[8..15], w2b[0..7], w2b[8..15]
-    const int half = part >> 1, u0 = (part & 1) * 8;
-    const int soff = ((nc0 * 4 + swid) * (Kp2 / 16) + half * 16) * 1024;
+  auto load_w2_part = [&](int part) {
 #pragma unroll
-    for (int u = u0; u < u0 + 8; ++u) (half ? w2b : w2a)[u] = f2_ldw(r2, voffL, soff + u * 1024);
+    for (int e = 0; e < 8; ++e) {
+      const int f = part * 8 + e;   // fragment f of the fill: k-step f / NCH of tile f % NCH
+      w2r[f / NCH][f % NCH] = f2_ldw(r2, voffL, w2s[f % NCH] + (f / NCH) * 1024);
+    }
   };
   {
     const char* x1_lane = X1 + l32 * g.X1S + hi * 16;
@@ -372,129 +371,159 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     }
   }
   __syncthreads();
-  if (a.c.h1save && qs == 0) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, true);
+  if (a.c.h1save && qs == 0) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, 0);
   stamp(3);
 
-  // ------------------------------------------------------------------ 4./5. conv2 chunks feeding conv3
-  f32x4 acc3[NT3][MT_O];
-#pragma unroll
-  for (int i = 0; i < NT3; ++i)
-#pragma unroll
-    for (int j = 0; j < MT_O; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // conv3 B operand: byte offset into the h2 chunk image per (tap, output m-tile); lane constants
-  int c3_off[9][MT_O];
-#pragma unroll
-  for (int mo = 0; mo < MT_O; ++mo) {
-    const int po = mo * 16 + r16;
-    const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = (rem >> lw) + halo, xx = rem & (W - 1);
-    const int base = sm * g.RH * W;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const int rn = rr + dy, xn = xx + dx;
-      const bool ok = (unsigned)rn < (unsigned)g.RH && (unsigned)xn < (unsigned)W;
-      const int rc = min(max(rn, 0), g.RH - 1), xc = min(max(xn, 0), W - 1);
-      c3_off[tap][mo] = ok ? (int)g.oH2c + f2_h2_off(base + rc * W + xc, wid * 4 + q4) : (int)g.oZero;
-    }
-  }
-  bf16x8f w3[9][NT3];
-  auto load_w3 = [&](int nc, int tap) {   // k-step (of 32) tap*16 + nc*4 + swid of every row tile; rows behind Cout are zero
+  // ------------------------------------------------------------------ 4. conv2: ONE pass over k for all of the wave's channel tiles
+  // Every B fragment (32 pixels x 16 k of h1) read from LDS feeds NCH MFMAs per pixel tile instead of one: the LDS
+  // array, which a chunk-by-chunk order keeps saturated (each wave re-reads all of h1 once per chunk), runs at 1/NCH of
+  // that, and the phase is bounded by the MFMAs.  W2 fragments stream from L2 through the register ring, each slot
+  // reloaded IN PLACE right after its last use with the fragment RD k-steps ahead (thousands of cycles: an L2 miss to
+  // the Infinity Cache / HBM is covered); the loads sit between the MFMAs, so the vector-memory issue (16 cycles per
+  // KiB and CU) stays under them instead of stalling all four waves in a burst.
+  // conv3's weight fragments: a register ring D3 chunks deep (all four chunks when conv3 has one row tile).  The first
+  // fill is requested as soon as conv2's k loop ends, so that it travels under conv2's epilogue (a stretch of pure VALU
+  // work with nothing else on the vector-memory path): one chunk ahead the loop waited on every tap for a load issued
+  // only nine taps earlier.
+  constexpr int D3 = (NT3 == 1 ? 4 : (NT3 == 2 ? 2 : 1)) < NCH ? (NT3 == 1 ? 4 : (NT3 == 2 ? 2 : 1)) : NCH;
+  bf16x8f w3[D3][9][NT3];
+  auto load_w3 = [&](int slot, int nc, int tap) {   // k-step (of 32) tap*16 + nc*4 + swid of every row tile; rows behind Cout are zero
 #pragma unroll
     for (int nt = 0; nt < NT3; ++nt)
-      w3[tap][nt] = f2_ldw(r3, voffL, (nt * (Kp3 / 32) + tap * 16 + nc * 4 + swid) * 1024);
+      w3[slot][tap][nt] = f2_ldw(r3, voffL, (nt * (Kp3 / 32) + tap * 16 + nc * 4 + swid) * 1024);
   };
+  {
+    // h1 B-fragment address: px = mt*32 + l32 (px & 15 == l32 & 15), slot = 2*ks + hi:
+    //   px*1024 + ((((2ks) & 15) ^ pc) | ((2ks) & 48)) * 16   with the lane constant pc = (l32 & 15) ^ hi
+    // the XOR term takes 8 values per lane (k-step mod 8): 8 lane-constant addresses; m-tile and k-step/8 are immediates
+    const int pc = (l32 & 15) ^ hi;
+    const char* h1r[8];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) load_w3(nc0, tap);   // first chunk; later chunks are reloaded in place by conv3
-  // h1 B-fragment address: px = mt*32 + l32 (px & 15 == l32 & 15), slot = 2*ks + hi:
-  //   px*1024 + ((((2ks) & 15) ^ pc) | ((2ks) & 48)) * 16   with the lane constant pc = (l32 & 15) ^ hi
-  // the XOR term takes 8 values per lane (k-step mod 8): 8 lane-constant addresses; m-tile and k-step/8 are immediates
-  const int pc = (l32 & 15) ^ hi;
-  const char* h1r[8];
+    for (int e = 0; e < 8; ++e) h1r[e] = H1 + l32 * 1024 + (((2 * e) ^ pc) << 4);
+    f32x16 acc2[NCH][MT32];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) h1r[e] = H1 + l32 * 1024 + (((2 * e) ^ pc) << 4);
-  f32x16 acc2[MT32];
-  // h2 chunk write address: px*256 + (((wid*4 + gi) ^ px) & 15) * 16 + 8*hi
-  char* h2w[MT32];
-  int h2ws[4];
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
-  for (int mt = 0; mt < MT32; ++mt) h2w[mt] = H2c + (mt * 32 + l32) * 256 + 8 * hi;
+      for (int mt = 0; mt < MT32; ++mt)
 #pragma unroll
-  for (int gi = 0; gi < 4; ++gi) h2ws[gi] = (((wid * 4 + gi) ^ l32) & 15) << 4;
-  // The weight streams are reloaded IN PLACE between the MFMAs: right after its last use a W2 fragment register
-  // receives the same fragment of the next chunk, and conv3 does the same with its W3 fragments: every weight byte is
-  // requested a whole chunk (thousands of cycles: an L2 miss to the Infinity Cache / HBM is covered) before its use, and
-  // one load per k-step keeps the vector-memory issue (16 cycles per KiB and CU) under the MFMAs instead of stalling
-  // all four waves in a burst.
-  auto conv2_half = [&](int half, bf16x8f (&fa)[16], int nc, int nn) {
-    const int soff_next = ((nn * 4 + swid) * (Kp2 / 16) + half * 16) * 1024;
+        for (int r = 0; r < 16; ++r) acc2[i][mt][r] = 0.f;
     bf16x8f fb[2][MT32];
-    auto rd2 = [&](int u, bf16x8f (&f)[MT32]) {
-      const int ks = half * 16 + u;
+    auto rd2 = [&](int ks, bf16x8f (&f)[MT32]) {
 #pragma unroll
       for (int mt = 0; mt < MT32; ++mt)
         f[mt] = *reinterpret_cast<const bf16x8f*>(h1r[ks & 7] + mt * 32768 + (ks >> 3) * 256);
     };
     rd2(0, fb[0]);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      if (u + 1 < 16) rd2(u + 1, fb[(u + 1) & 1]);
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks + 1 < 32) rd2(ks + 1, fb[(ks + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < MT32; ++mt)
-        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], fb[u & 1][mt], acc2[mt], 0, 0, 0);
-      fa[u] = f2_ldw(r2, voffL, soff_next + u * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto conv3_chunk = [&](int nn) {
-    // a tap is only 4*NT3 short MFMAs: the LDS reads run three taps ahead
-    bf16x8f fb[4][MT_O];
-    auto rd3 = [&](int tap, bf16x8f (&f)[MT_O]) {
+      for (int i = 0; i < NCH; ++i) {
 #pragma unroll
-      for (int mo = 0; mo < MT_O; ++mo) f[mo] = *reinterpret_cast<const bf16x8f*>(smem_f2 + c3_off[tap][mo]);
-    };
-    rd3(0, fb[0]);
-    rd3(1, fb[1]);
-    rd3(2, fb[2]);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap + 3 < 9) rd3(tap + 3, fb[(tap + 3) & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mo = 0; mo < MT_O; ++mo)
-#pragma unroll
-        for (int nt = 0; nt < NT3; ++nt)
-          acc3[nt][mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[tap][nt], fb[tap & 3][mo], acc3[nt][mo], 0, 0, 0);
-      load_w3(nn, tap);
+        for (int mt = 0; mt < MT32; ++mt)
+          acc2[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[ks % RD][i], fb[ks & 1][mt], acc2[i][mt], 0, 0, 0);
+        if (ks + RD < 32) w2r[ks % RD][i] = f2_ldw(r2, voffL, w2s[i] + (ks + RD) * 1024);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  for (int nc = nc0; nc < nc0 + NCH; ++nc) {
-    const int nn = min(nc + 1, nc0 + NCH - 1);   // prefetches are unconditional (clamped): loads under a branch defeat vmcnt counting
 #pragma unroll
-    for (int mt = 0; mt < MT32; ++mt)
+    for (int c = 0; c < D3; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
-    conv2_half(0, w2a, nc, nn);
-    conv2_half(1, w2b, nc, nn);
-    if (nc > nc0) __syncthreads();
-    // every wave is done with the previous chunk image (conv3 and the h2 copy-out)
-    const int nl = wid * 32 + 4 * hi;
+      for (int tap = 0; tap < 9; ++tap) load_w3(c, nc0 + c, tap);
+    __syncthreads();   // every wave is done reading h1: h2 takes its place in the same image (same layout)
+    // h2 write address: px*1024 + ((nc0 + i)*16 + ((wid*4 + gi) ^ px) & 15) * 16 + 8*hi
+    char* h2w[MT32];
+    int h2ws[4];
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int n = nc * 128 + nl + 8 * gi;
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(Pb2 + n), es = *reinterpret_cast<const f32x4*>(Pe2 + n);
+    for (int mt = 0; mt < MT32; ++mt) h2w[mt] = H1 + (mt * 32 + l32) * 1024 + nc0 * 256 + 8 * hi;
 #pragma unroll
-      for (int mt = 0; mt < MT32; ++mt) {
-        const f32x2 v0 = f32x2{acc2[mt][4 * gi], acc2[mt][4 * gi + 1]} * f32x2{es[0], es[1]} + f32x2{bb[0], bb[1]};
-        const f32x2 v1 = f32x2{acc2[mt][4 * gi + 2], acc2[mt][4 * gi + 3]} * f32x2{es[2], es[3]} + f32x2{bb[2], bb[3]};
-        const u32x2f pk = {f2_relu_pack(v0) & hmask[mt], f2_relu_pack(v1) & hmask[mt]};   // zero padding of conv3
-        *reinterpret_cast<u32x2f*>(h2w[mt] + h2ws[gi]) = pk;
+    for (int gi = 0; gi < 4; ++gi) h2ws[gi] = (((wid * 4 + gi) ^ l32) & 15) << 4;
+    const int nl = nc0 * 128 + wid * 32 + 4 * hi;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int n = nl + i * 128 + 8 * gi;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(Pb2 + n), es = *reinterpret_cast<const f32x4*>(Pe2 + n);
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt) {
+          const f32x2 v0 = f32x2{acc2[i][mt][4 * gi], acc2[i][mt][4 * gi + 1]} * f32x2{es[0], es[1]} + f32x2{bb[0], bb[1]};
+          const f32x2 v1 =
+              f32x2{acc2[i][mt][4 * gi + 2], acc2[i][mt][4 * gi + 3]} * f32x2{es[2], es[3]} + f32x2{bb[2], bb[3]};
+          const u32x2f pk = {f2_relu_pack(v0) & hmask[mt], f2_relu_pack(v1) & hmask[mt]};   // zero padding of conv3
+          *reinterpret_cast<u32x2f*>(h2w[mt] + i * 256 + h2ws[gi]) = pk;
+        }
+      }
+  }
+  __syncthreads();
+  if (a.c.h2save) {
+    if (NCH == 4) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), 0, H1, 6, 0);
+    else
+      for (int i = 0; i < NCH; ++i) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), (nc0 + i) * 128, H1, 4, (nc0 + i) * 16);
+  }
+
+  // ------------------------------------------------------------------ 5. conv3 over the wave's K-slices of h2
+  // 3x3 512->Cout: 9 taps = shifted rows of the h2 image; for every 128-channel chunk wave w takes the chunk's w-th 32
+  // channels (one 16x16x32 k-step) for all 9 taps; the four waves' sums are reduced through LDS in 6.
+  f32x4 acc3[NT3][MT_O];
+#pragma unroll
+  for (int i = 0; i < NT3; ++i)
+#pragma unroll
+    for (int j = 0; j < MT_O; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    // B operand: byte offset into the image per (tap, output m-tile) for chunk nc0; lane constants.  Chunk nc0 + i is
+    // 256*i bytes further (an immediate); taps that fall outside the image read the zero slot, which therefore exists
+    // once per chunk, at the same 256-byte pitch.
+    // (unsigned arithmetic: a tap outside the image gives a meaningless pixel index, which the select discards)
+    int c3_off[9][MT_O];
+    const unsigned k4 = (unsigned)(wid * 4 + q4), zoff = (unsigned)g.oZero + (unsigned)nc0 * 256u;
+    const unsigned ioff = (unsigned)g.oH1 + (unsigned)nc0 * 256u;
+#pragma unroll
+    for (int mo = 0; mo < MT_O; ++mo) {
+      const int po = mo * 16 + r16;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = (rem >> lw) + halo, xx = rem & (W - 1);
+      const unsigned px0 = (unsigned)(sm * g.RH * W + rr * W + xx);
+      unsigned rok[3], xok[3];   // all-ones / zero masks (selects by mask: conditions here otherwise become 36 branches)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        rok[d] = 0u - (unsigned)((unsigned)(rr + d - 1) < (unsigned)g.RH);
+        xok[d] = 0u - (unsigned)((unsigned)(xx + d - 1) < (unsigned)W);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const unsigned px = px0 + (unsigned)(dy * W + dx);
+        const unsigned addr = ioff + (px << 10) + (((k4 ^ px) & 15u) << 4);
+        c3_off[tap][mo] = (int)(zoff ^ ((addr ^ zoff) & rok[dy + 1] & xok[dx + 1]));
       }
     }
-    __syncthreads();
-    if (a.c.h2save) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), nc * 128, H2c, 4, false);
-    conv3_chunk(nn);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      // a tap is only 4*NT3 short MFMAs: the LDS reads run three taps ahead
+      bf16x8f fb[4][MT_O];
+      auto rd3 = [&](int tap, bf16x8f (&f)[MT_O]) {
+#pragma unroll
+        for (int mo = 0; mo < MT_O; ++mo)
+          f[mo] = *reinterpret_cast<const bf16x8f*>(smem_f2 + c3_off[tap][mo] + i * 256);
+      };
+      rd3(0, fb[0]);
+      rd3(1, fb[1]);
+      rd3(2, fb[2]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 3 < 9) rd3(tap + 3, fb[(tap + 3) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mo = 0; mo < MT_O; ++mo)
+#pragma unroll
+          for (int nt = 0; nt < NT3; ++nt)
+            acc3[nt][mo] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[i % D3][tap][nt], fb[tap & 3][mo], acc3[nt][mo], 0, 0, 0);
+        if (i + D3 < NCH) load_w3(i % D3, nc0 + i + D3, tap);   // in place, D3 chunks ahead
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
   __syncthreads();
   stamp(4);
