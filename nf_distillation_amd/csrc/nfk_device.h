@@ -37,12 +37,20 @@ __device__ __forceinline__ float log_sigmoidf(float t) {
   return t >= 0.f ? -log1pf(expf(-t)) : t - log1pf(expf(t));
 }
 
-// Sum of S split-K slabs at one element, fixed order.  Loads are issued 8 (then 4) at a time so their
+// Sum of S split-K slabs at one element, fixed order.  Loads are issued 16 (then 8, then 4) at a time so their
 // latencies overlap instead of forming an S-deep dependent chain.
 __device__ __forceinline__ float slab_sum(const float* __restrict__ a3, int S, long stride, long off) {
   const float* p = a3 + off;
   float v = 0.f;
   int s = 0;
+  for (; s + 16 <= S; s += 16) {   // two groups of 8 in flight; the adds keep the order of the one-group loop below
+    float t[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) t[e] = p[e * stride];
+    v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    v += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
+    p += 16 * stride;
+  }
   for (; s + 8 <= S; s += 8) {
     const float t0 = p[0], t1 = p[stride], t2 = p[2 * stride], t3 = p[3 * stride];
     const float t4 = p[4 * stride], t5 = p[5 * stride], t6 = p[6 * stride], t7 = p[7 * stride];

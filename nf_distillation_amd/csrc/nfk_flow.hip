@@ -855,6 +855,28 @@ __global__ void __launch_bounds__(256) prior_bwd_kernel(PriorBwdArgs a) {
   }
 }
 
+// Column `col` of the partial rows rg, rg + 8, ... of a [rows][2][n] array, summed in that order.  Eight rows' loads
+// are issued before the first add: a plain loop waits for every pair of loads in turn, and with up to 256 partial rows
+// (chained backward: one per channel-mix workgroup) that was a chain of 32 memory latencies.
+__device__ __forceinline__ void partial_rows_sum(const float* __restrict__ src, int rows, int n, int col, int rg, float& s0,
+                                                 float& s1) {
+  int i = rg;
+  for (; i + 56 < rows; i += 64) {
+    float u[8], v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      u[e] = src[((long)(i + 8 * e) * 2) * n + col];
+      v[e] = src[((long)(i + 8 * e) * 2 + 1) * n + col];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0 += u[e]; s1 += v[e]; }
+  }
+  for (; i < rows; i += 8) {
+    s0 += src[((long)i * 2) * n + col];
+    s1 += src[((long)i * 2 + 1) * n + col];
+  }
+}
+
 // Finalise the small per-channel parameter gradients of one coupling net (accumulates):
 //   colsum layout from conv_gemm EPI_DGRAD: [mblocks][2][N] = (sum acc*h , sum masked*scale)
 //   tail layout from coupling_bwd / split_bwd: [B][2][Cout] = (sum g_a3, 3 sum g_h h)
@@ -871,10 +893,7 @@ __global__ void __launch_bounds__(256) small_grads_kernel(SmallGradArgs a) {
   if (blockIdx.x * 32 >= n) return;
   float s0 = 0.f, s1 = 0.f;
   if (col < n)
-    for (int i = rg; i < rows; i += 8) {
-      s0 += src[((long)i * 2) * n + col];
-      s1 += src[((long)i * 2 + 1) * n + col];
-    }
+    partial_rows_sum(src, rows, n, col, rg, s0, s1);
   red[0][rg][threadIdx.x & 31] = s0;
   red[1][rg][threadIdx.x & 31] = s1;
   __syncthreads();
@@ -902,10 +921,7 @@ __device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const Ste
     if (bx * 32 >= n) return;
     float s0 = 0.f, s1 = 0.f;
     if (col < n)
-      for (int i = rg; i < rows; i += 8) {
-        s0 += src[((long)i * 2) * n + col];
-        s1 += src[((long)i * 2 + 1) * n + col];
-      }
+      partial_rows_sum(src, rows, n, col, rg, s0, s1);
     red[0][rg][threadIdx.x & 31] = s0;
     red[1][rg][threadIdx.x & 31] = s1;
     __syncthreads();
