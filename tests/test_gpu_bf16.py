@@ -14,8 +14,10 @@ from test_oracle_golden import full_shapes
 pytestmark = pytest.mark.gpu
 
 
-def build(cfg, sd):
+def build(cfg, sd, seed=None):
     import nf_distillation_amd as nfa
+    if seed is not None:   # `shuffle` permutations are drawn at construction and are not part of the state_dict
+        torch.manual_seed(seed)
     model = nfa.create_glow_model(dict(cfg))
     model.load_state_dict({k: v.clone() for k, v in sd.items()})
     return model.cuda().set_compute_dtype("bf16")
@@ -105,9 +107,13 @@ def _fused_vs_unfused(name):
         x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 5)
     else:
         sd, x, noise = g.group("sd"), g.t("x"), g.t("noise")
+    _compare_fused_unfused(cfg, sd, x, noise)
+
+
+def _compare_fused_unfused(cfg, sd, x, noise, seed=None):
     res = []
     for fused in (True, False):
-        model = build(cfg, sd).set_fused(fused)
+        model = build(cfg, sd, seed).set_fused(fused)
         outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
         bpd.mean().backward()
         torch.cuda.synchronize()
@@ -125,6 +131,61 @@ def _fused_vs_unfused(name):
         if float(g0[k].abs().max()) > 0:
             assert rel_err(g1[k], g0[k]) < 0.1, (k, rel_err(g1[k], g0[k]))
     assert num / (da ** 0.5 * db ** 0.5) > 0.9995
+
+
+def _random_parameters(cfg, seed):
+    """state_dict of a model of this configuration with every parameter drawn at random (the reference initialises the
+    last conv of each coupling net to zero, which would make the coupling trivial); buffers keep their initial values"""
+    import math
+    import nf_distillation_amd as nfa
+    model = nfa.create_glow_model(dict(cfg))
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            leaf = k.split(".")[-1]
+            r = torch.randn(p.shape, generator=gen)
+            if leaf in ("lower", "upper"):
+                p.copy_(r * 0.3 / math.sqrt(p.shape[0]))
+            elif k.endswith("invconv.weight"):
+                q, _ = torch.linalg.qr(torch.randn(p.shape, generator=gen, dtype=torch.float64))
+                p.copy_(q.float() + 0.05 * r)
+            elif leaf == "weight":      # conv weights [out, in, kh, kw]
+                p.copy_(r * 0.7 / math.sqrt(p.shape[1] * p.shape[2] * p.shape[3]))
+            else:                       # biases, logs, log_s, prior
+                p.copy_(r * 0.1)
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+VARIANTS = {
+    # hidden 512 = the fused kernel's shape; batches that leave ragged tiles at level 3 (4 images per workgroup)
+    "affine_B5": dict(flow_coupling="affine", flow_permutation="invconv", LU_decomposed=True, B=5),
+    "additive_B3": dict(flow_coupling="additive", flow_permutation="invconv", LU_decomposed=True, B=3),
+    "shuffle_B6": dict(flow_coupling="affine", flow_permutation="shuffle", LU_decomposed=True, B=6),
+    "reverse_dense_B1": dict(flow_coupling="affine", flow_permutation="reverse", LU_decomposed=False, B=1),
+    "dense_invconv_B2": dict(flow_coupling="affine", flow_permutation="invconv", LU_decomposed=False, B=2),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_fused_step_variants(variant):
+    """Coupling type, permutation type and ragged batches through the one-launch FlowStep (hidden 512, K=2, L=3, 32x32):
+    against the five-kernel bf16 path (same roundings) and, for bits/dim, against this engine's fp32 parity mode (which
+    the fp32 tests pin to the oracle at 1e-5): BASELINE.json's 0.01 bpd bar."""
+    import nf_distillation_amd as nfa
+    v = dict(VARIANTS[variant])
+    B = v.pop("B")
+    cfg = {"image_shape": [32, 32, 3], "hidden_channels": 512, "K": 2, "L": 3, "actnorm_scale": 1.0, "y_classes": 10,
+           "learn_top": False, "y_condition": False, "is_1d": False, **v}
+    sd = _random_parameters(cfg, 11 + B)
+    x, noise = synthetic_images(B, (3, 32, 32), seed=100 + B)
+    _compare_fused_unfused(cfg, sd, x, noise, seed=77)
+    torch.manual_seed(77)
+    m32 = nfa.create_glow_model(dict(cfg))
+    m32.load_state_dict({k: t.clone() for k, t in sd.items()})
+    with torch.no_grad():
+        _, bpd32, _ = m32.cuda()(x.clone().cuda(), None, noise=noise.cuda())
+        _, bpd16, _ = build(cfg, sd, 77)(x.clone().cuda(), None, noise=noise.cuda())
+    assert float((bpd16 - bpd32).abs().max()) < 0.01, (bpd16, bpd32)
 
 
 def _grads_with(mode, halo, g, cfg, sd, x, noise, chain=False):
