@@ -222,15 +222,22 @@ def test_dual_dgrad_wgrad_launch_is_bit_identical():
             assert torch.equal(res[0][k], other[k]), k
 
 
-def test_chained_backward_equals_per_step_calls():
+@pytest.mark.parametrize("coupling", ["affine", "additive"])
+def test_chained_backward_equals_per_step_calls(coupling):
     """nfk_step2d_bwd_chain folds the next step's coupling backward into the launch that ends the current step's.  The
     element-wise results are the same numbers; only the per-channel sums behind block.4's bias / logs gradients are
     reduced over pixel tiles instead of over samples.  Everything else must agree bit for bit."""
     g = Golden("cifar_k8_full")
     cfg = g.cfg
-    sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+    if coupling == "affine":
+        sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+        B = int(g.t("batch"))
+    else:   # additive coupling (Cout = C/2), a batch that leaves ragged tiles
+        cfg = dict(cfg, flow_coupling="additive", K=3)
+        sd = _random_parameters(cfg, 5)
+        B = 5
     h, w, c = cfg["image_shape"]
-    x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 9)
+    x, noise = synthetic_images(B, (c, h, w), seed=int(g.t("seed")) + 9)
     a = _grads_with(2, True, g, cfg, sd, x, noise, chain=True)
     b = _grads_with(2, True, g, cfg, sd, x, noise, chain=False)
     n_sum = 0
