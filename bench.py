@@ -218,8 +218,9 @@ def main():
         # HIP events bracket each launch: eager steps (outside the captured graph), on ONE stream, so that a launch's
         # duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r01_e_*)
         step.enable_concurrency(False)
-        if pipelined:   # the frozen teacher runs its deep-level fused steps with the pipelined schedule's 2-way split
+        if pipelined:   # both models run their deep-level fused steps with the pipelined schedule's split policy
             teacher.flow.engine().fused_split_inference = runner.teacher_split
+            student.flow.engine().fused_split_training = runner.student_split
         run(2, eager=True)
         capi.profile_begin()
         run(args.steps, eager=True)

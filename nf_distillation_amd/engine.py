@@ -57,6 +57,7 @@ class FlowEngine:
         # hidden split of the fused step on small grids also for passes that keep nothing (a frozen teacher): on the
         # critical path it shortens the step; beside another chain (pipeline.py) it only takes CUs away from that chain
         self.fused_split_inference = 4   # ways: 4, 2, 0 (none) or "frugal" (see _EncodeFn.forward)
+        self.fused_split_training = 4    # the same for a forward that keeps what the backward needs
         self.chain_backward = True       # nfk_step2d_bwd_chain (False: one independent nfk_step2d_bwd call per step)
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
@@ -533,8 +534,8 @@ class _EncodeFn(torch.autograd.Function):
                     saved.append((cur, zb, h1, h2, hs, arena))
                 else:
                     saved.append(None)
-                # hidden split of this launch: 4-way when a backward follows (critical path), else the engine's policy
-                ways = 4 if need else eng.fused_split_inference
+                # hidden split of this launch: the engine's policy for a training / an inference forward
+                ways = eng.fused_split_training if need else eng.fused_split_inference
                 if ways == "frugal":   # beside another chain: only the grids that would fill fewer than 32 CUs
                     ways = 4 if (B * r.H * r.W + 63) // 64 < 32 else 0
                 lib.nfk_fused_set_split(int(ways))   # host-side launch parameter
