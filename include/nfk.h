@@ -142,6 +142,10 @@ int nfk_repack_batch(const nfk_repack_desc *descs, int n, void *stream);
 /* same, to bf16 with k padded to 64 (throughput mode: nfk_step2d.bf16 = 1) */
 int nfk_repack_batch_bf16(const nfk_repack_desc *descs, int n, void *stream);
 int nfk_padded_k_bf16(int K);
+/* nfk_prep + nfk_repack_batch(f32_descs) + nfk_repack_batch_bf16(bf16_descs) in ONE launch (the head of every training
+ * step in bf16 mode: the three are independent of each other).  Any of the three may be empty. */
+int nfk_prep_repack(const nfk_prep_desc *descs, int nsteps, int want_inverse, const nfk_repack_desc *f32_descs, int n_f32,
+                    const nfk_repack_desc *bf16_descs, int n_bf16, void *stream);
 
 /* ---- op-level entry points (unit-testable primitives) -------------------------------------- */
 /* z[m][:] = Wm x[m][:] + cv   -- _ActNorm.forward + InvertibleConv1x1.forward / Permute2d

@@ -111,6 +111,7 @@ _PROTOS = {
     "nfk_repack_batch": (i32, [vp, i32, vp]),
     "nfk_repack_batch_bf16": (i32, [vp, i32, vp]),
     "nfk_padded_k_bf16": (i32, [i32]),
+    "nfk_prep_repack": (i32, [vp, i32, i32, vp, i32, vp, i32, vp]),
     "nfk_chanmix": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp]),
     "nfk_conv": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
     "nfk_coupling_fwd": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -120,6 +120,10 @@ size_t nfk_split2d_bwd_ws_floats(const nfk_split2d* s) {
 int nfk_prep(const nfk_prep_desc* descs, int nsteps, int want_inverse, void* stream) {
   return launch_prep(descs, nsteps, want_inverse, S_(stream));
 }
+int nfk_prep_repack(const nfk_prep_desc* descs, int nsteps, int want_inverse, const nfk_repack_desc* f32_descs, int n_f32,
+                    const nfk_repack_desc* bf16_descs, int n_bf16, void* stream) {
+  return launch_prep_repack(descs, nsteps, want_inverse, f32_descs, n_f32, bf16_descs, n_bf16, S_(stream));
+}
 int nfk_prep_bwd(const nfk_prep_desc* descs, const nfk_prep_grad* grads, int nsteps, const float* g_logdet, int B,
                  int any_dense, void* stream) {
   return launch_prep_bwd(descs, grads, nsteps, g_logdet, B, any_dense, S_(stream));

@@ -14,6 +14,7 @@
 // plus the inverse and backward of each.  Log-det sums use one workgroup per sample with a
 // fixed-order wave/LDS tree (no atomics), so results are bitwise reproducible run to run.
 #include "nfk_internal.h"
+#include "nfk_repack.h"
 
 namespace nfk {
 
@@ -175,6 +176,26 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) float pf_lds[];
   if ((size_t)6 * d.C * d.C * sizeof(float) <= PREP_LDS) prep_body(d, want_inverse, pf_lds, true, sh);
   else prep_body(d, want_inverse, d.scratch, false, sh);
+}
+
+// Everything a forward needs from the parameters in ONE launch: the steps' prep (first n_prep workgroups: one latency
+// chain of ~40 us each) and, beside them, the conv weight repacks (64 workgroups per weight; f32 descriptors first).
+// As separate launches on one stream the three ran one after the other at the head of every training step.
+__global__ void __launch_bounds__(256) prep_repack_kernel(const PrepDesc* __restrict__ descs, int n_prep, int want_inverse,
+                                                          const nfk_repack_desc* __restrict__ rf32, int n_f32,
+                                                          const nfk_repack_desc* __restrict__ rbf16) {
+  __shared__ float sh[32];
+  extern __shared__ __attribute__((aligned(16))) float pf_lds[];
+  const int b = blockIdx.x;
+  if (b < n_prep) {
+    const PrepDesc d = descs[b];
+    if ((size_t)6 * d.C * d.C * sizeof(float) <= PREP_LDS) prep_body(d, want_inverse, pf_lds, true, sh);
+    else prep_body(d, want_inverse, d.scratch, false, sh);
+    return;
+  }
+  const int r = b - n_prep, w = r >> 6, bx = r & 63;
+  if (w < n_f32) repack_f32_body(rf32[w], bx, 64);
+  else repack_bf16_body(rbf16[w - n_f32], bx, 64, pf_lds);
 }
 
 // In-place reduction of the per-workgroup partial (gWf, gcf) slabs of every step into slab 0:
@@ -968,6 +989,23 @@ static inline int ew_blocks(long total) {
 // threads for a one-workgroup-per-sample kernel over n elements
 static inline int sample_threads(int n) { return n >= 1024 ? 1024 : (n > 256 ? ((n + 63) / 64) * 64 : 256); }
 
+int launch_prep_repack(const PrepDesc* descs_dev, int nsteps, int want_inverse, const nfk_repack_desc* rf32, int n_f32,
+                       const nfk_repack_desc* rbf16, int n_bf16, hipStream_t st) {
+  static_assert(PREP_LDS >= RP_LDS_FLOATS * sizeof(float), "the repack tile lives in the prep launch's LDS");
+  const int grid = nsteps + 64 * (n_f32 + n_bf16);
+  if (grid <= 0) return NFK_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(prep_repack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)PREP_LDS) != hipSuccess)
+      return NFK_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(prep_repack_kernel, dim3(grid), dim3(256), PREP_LDS, st, descs_dev, nsteps, want_inverse, rf32, n_f32,
+                     rbf16);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
 int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st) {
   if (nsteps <= 0) return NFK_OK;
   hipLaunchKernelGGL(prep_kernel, dim3(nsteps), dim3(256), PREP_LDS, st, descs_dev, want_inverse);

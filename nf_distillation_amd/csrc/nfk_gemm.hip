@@ -15,6 +15,7 @@
 // The accumulator then holds 4 consecutive channels of one pixel per lane, so epilogues are
 // float4-wide and per-channel parameters load as float4.
 #include "nfk_internal.h"
+#include "nfk_repack.h"
 #include <vector>
 
 namespace nfk {
@@ -493,25 +494,8 @@ __global__ void repack_kernel(const float* __restrict__ W, int Cout, int Cin, in
   }
 }
 
-__global__ void repack_batch_kernel(const nfk_repack_desc* __restrict__ descs) {
-  const nfk_repack_desc d = descs[blockIdx.y];
-  const int Kp = (d.taps * d.Cin + BK - 1) / BK * BK, Kpd = (d.taps * d.Cout + BK - 1) / BK * BK;
-  const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
-  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total_f + total_d;
-       t += (long)gridDim.x * blockDim.x) {
-    if (t < total_f) {
-      const int co = t / Kp, k = t % Kp;
-      float v = 0.f;
-      if (k < d.taps * d.Cin) v = d.w[((long)co * d.Cin + k % d.Cin) * d.taps + k / d.Cin];
-      d.wt[t] = v;
-    } else {
-      const long u = t - total_f;
-      const int ci = u / Kpd, k = u % Kpd;
-      float v = 0.f;
-      if (k < d.taps * d.Cout) v = d.w[((long)(k % d.Cout) * d.Cin + ci) * d.taps + (d.taps - 1 - k / d.Cout)];
-      d.wd[u] = v;
-    }
-  }
+__global__ void __launch_bounds__(256) repack_batch_kernel(const nfk_repack_desc* __restrict__ descs) {
+  repack_f32_body(descs[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // wgrad finalize: gradW[co][ci][tap] += sum_slabs out[s][co][tap*Cin + ci]   (fixed order)

@@ -8,6 +8,7 @@
 //   * accumulation, ActNorm scale/bias, ReLU, masks and per-channel sums stay fp32; narrow inputs
 //     (z1, g_a3: C <= 96 channels) stay fp32 in HBM and are converted while staging (XF32)
 #include "nfk_internal.h"
+#include "nfk_repack.h"
 
 namespace nfk {
 
@@ -327,59 +328,9 @@ __global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
   conv_gemm_bf16_body<TN, TM, WN, WM, XF32>(a, blockIdx.x, gridDim.y, blockIdx.y);
 }
 
-// conv.weight [Cout][Cin][taps] (fp32) -> bf16 wt [Cout][Kp64] and wd [Cin][Kp64(taps*Cout)] (flipped taps)
 __global__ void __launch_bounds__(256) repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ descs) {
-  // one thread = 8 consecutive output elements (one 16-byte store); 32-bit index math, one division per 8 elements
-  const nfk_repack_desc d = descs[blockIdx.y];
-  const int K = d.taps * d.Cin, Kd = d.taps * d.Cout;
-  const int Kp = (K + BKH - 1) / BKH * BKH, Kpd = (Kd + BKH - 1) / BKH * BKH;
-  const int rows_g = (d.frag == 1) ? d.Cout : (d.Cout + 15) / 16 * 16;
-  const int n8_f = d.Cout * (Kp / 8), n8_d = d.wd ? d.Cin * (Kpd / 8) : 0;
-  const int n8_g = (d.wf && d.frag) ? rows_g * (Kp / 8) : 0;
-  __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
-  __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
-  __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < n8_f + n8_d + n8_g; t += gridDim.x * 256) {
-    float v[8];
-    __bf16* dst;
-    if (t < n8_f + n8_g) {
-      // forward layouts: value(co, k) = w[co][k % Cin][k / Cin], zero outside
-      int co, k0;
-      if (t < n8_f) {                       // row-major [Cout][Kp]
-        co = t / (Kp / 8); k0 = (t - co * (Kp / 8)) * 8;
-        dst = wt + (long)t * 8;
-      } else {                              // fragment order: 8 elements of lane `lane` of fragment `fr`
-        const int u = t - n8_f, lane = u & 63, fr = u >> 6;
-        if (d.frag == 1) {                  // 32x32x16 A fragments: 32 rows x 16 k
-          const int KS = Kp / 16, nt = fr / KS, ks = fr - nt * KS;
-          co = nt * 32 + (lane & 31); k0 = ks * 16 + (lane >> 5) * 8;
-        } else {                            // 16x16x32 A fragments: 16 rows x 32 k
-          const int KS = Kp / 32, nt = fr / KS, ks = fr - nt * KS;
-          co = nt * 16 + (lane & 15); k0 = ks * 32 + (lane >> 4) * 8;
-        }
-        dst = wf + (long)u * 8;
-      }
-      int tap = k0 / d.Cin, ci = k0 - tap * d.Cin;
-      const float* wrow = d.w + (long)co * d.Cin * d.taps;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = (co < d.Cout && k0 + e < K) ? wrow[ci * d.taps + tap] : 0.f;
-        if (++ci == d.Cin) { ci = 0; ++tap; }
-      }
-    } else {
-      // dgrad layout [Cin][Kpd]: value(ci, k) = w[k % Cout][ci][taps - 1 - k / Cout]
-      const int u = t - n8_f - n8_g, ci = u / (Kpd / 8), k0 = (u - ci * (Kpd / 8)) * 8;
-      int tap = k0 / d.Cout, co = k0 - tap * d.Cout;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = (k0 + e < Kd) ? d.w[((long)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)] : 0.f;
-        if (++co == d.Cout) { co = 0; ++tap; }
-      }
-      dst = wd + (long)u * 8;
-    }
-    const u32x4b pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-    *reinterpret_cast<u32x4b*>(dst) = pk;
-  }
+  __shared__ float T[RP_LDS_FLOATS];
+  repack_bf16_body(descs[blockIdx.y], blockIdx.x, gridDim.x, T);
 }
 
 template <int TN, int TM, int WN, int WM>

@@ -153,6 +153,8 @@ int repack_batch(const nfk_repack_desc* descs, int n, hipStream_t st);
 int wgrad_finalize(const float* slabs, int S, long slab_stride, int Cout, int Cin, int taps, float* gradW,
                    hipStream_t st);
 int launch_prep(const PrepDesc* descs_dev, int nsteps, int want_inverse, hipStream_t st);
+int launch_prep_repack(const PrepDesc* descs_dev, int nsteps, int want_inverse, const nfk_repack_desc* rf32, int n_f32,
+                       const nfk_repack_desc* rbf16, int n_bf16, hipStream_t st);
 int launch_prep_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,
                     int any_dense, hipStream_t st);
 int launch_prep_inv_bwd(const PrepDesc* descs_dev, const PrepGrad* grads_dev, int nsteps, const float* gld, int B,

@@ -284,10 +284,13 @@ class FlowEngine:
         if fresh:
             return
         lib, s = capi.lib(), capi.stream()
-        check(lib.nfk_prep(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, s), "nfk_prep")
-        check(lib.nfk_repack_batch(ptr(st["repack_dev"]), st["n_repack"], s), "nfk_repack_batch")
-        repack = lib.nfk_repack_batch_bf16 if self.bf16 else lib.nfk_repack_batch
-        check(repack(ptr(st["step_repack_dev"]), st["n_step_repack"], s), "nfk_repack_batch(step convs)")
+        if self.bf16:   # one launch: prep of every step, the Split2d convs (f32) and the coupling nets' convs (bf16)
+            check(lib.nfk_prep_repack(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, ptr(st["repack_dev"]),
+                                      st["n_repack"], ptr(st["step_repack_dev"]), st["n_step_repack"], s), "nfk_prep_repack")
+        else:
+            check(lib.nfk_prep(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, s), "nfk_prep")
+            check(lib.nfk_repack_batch(ptr(st["repack_dev"]), st["n_repack"], s), "nfk_repack_batch")
+            check(lib.nfk_repack_batch(ptr(st["step_repack_dev"]), st["n_step_repack"], s), "nfk_repack_batch(step convs)")
         st["version"], st["has_inverse"] = ver, bool(want_inverse)
 
     # ------------------------------------------------------------------ public entry points

@@ -138,6 +138,7 @@ def _random_parameters(cfg, seed):
     last conv of each coupling net to zero, which would make the coupling trivial); buffers keep their initial values"""
     import math
     import nf_distillation_amd as nfa
+    torch.manual_seed(seed)   # the invconv buffers (p, sign_s) and shuffle indices come from the constructor's draws
     model = nfa.create_glow_model(dict(cfg))
     gen = torch.Generator().manual_seed(seed)
     with torch.no_grad():

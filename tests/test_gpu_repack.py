@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 # sizes, and shapes that no tile scheme divides
 CASES = [(512, 512, 1, 1), (512, 6, 9, 1), (512, 12, 9, 1), (512, 24, 9, 1), (512, 48, 9, 1),
          (12, 512, 9, 2), (24, 512, 9, 2), (48, 512, 9, 2), (96, 512, 9, 2), (6, 512, 9, 2),
-         (32, 32, 1, 1), (32, 6, 9, 1), (12, 32, 9, 2), (64, 40, 1, 1), (20, 10, 9, 0), (7, 13, 9, 2), (33, 70, 1, 0)]
+         (32, 32, 1, 1), (32, 6, 9, 1), (12, 32, 9, 2), (64, 40, 1, 1), (20, 10, 9, 0), (7, 13, 9, 2), (33, 70, 1, 0), (56, 64, 9, 2), (56, 64, 9, 0), (512, 72, 9, 1)]
 
 
 def _expected(w, frag, Kp, Kpd):
