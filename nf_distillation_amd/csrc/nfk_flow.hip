@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ 
 // Everything a forward needs from the parameters in ONE launch: the steps' prep (first n_prep workgroups: one latency
 // chain of ~40 us each) and, beside them, the conv weight repacks (64 workgroups per weight; f32 descriptors first).
 // As separate launches on one stream the three ran one after the other at the head of every training step.
-__global__ void __launch_bounds__(256) prep_repack_kernel(const PrepDesc* __restrict__ descs, int n_prep, int want_inverse,
+constexpr int PR_THREADS = 512;   // 60 KiB of LDS per workgroup leave room for two per CU: wider workgroups keep the CU's
+                                  // memory pipeline busy during the repack
+__global__ void __launch_bounds__(PR_THREADS) prep_repack_kernel(const PrepDesc* __restrict__ descs, int n_prep, int want_inverse,
                                                           const nfk_repack_desc* __restrict__ rf32, int n_f32,
                                                           const nfk_repack_desc* __restrict__ rbf16) {
   __shared__ float sh[32];
@@ -1001,7 +1003,7 @@ int launch_prep_repack(const PrepDesc* descs_dev, int nsteps, int want_inverse, 
       return NFK_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(prep_repack_kernel, dim3(grid), dim3(256), PREP_LDS, st, descs_dev, nsteps, want_inverse, rf32, n_f32,
+  hipLaunchKernelGGL(prep_repack_kernel, dim3(grid), dim3(PR_THREADS), PREP_LDS, st, descs_dev, nsteps, want_inverse, rf32, n_f32,
                      rbf16);
   NFK_LAUNCH_CHECK();
   return NFK_OK;

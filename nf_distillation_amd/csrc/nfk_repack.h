@@ -19,7 +19,7 @@ __device__ __forceinline__ unsigned rp_pack2(float lo, float hi) {
 __device__ __forceinline__ void repack_f32_body(const nfk_repack_desc& d, const int bx, const int nbx) {
   const int Kp = (d.taps * d.Cin + RP_BK - 1) / RP_BK * RP_BK, Kpd = (d.taps * d.Cout + RP_BK - 1) / RP_BK * RP_BK;
   const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
-  for (long t = bx * 256L + threadIdx.x; t < total_f + total_d; t += nbx * 256L) {
+  for (long t = bx * (long)blockDim.x + threadIdx.x; t < total_f + total_d; t += nbx * (long)blockDim.x) {
     if (t < total_f) {
       const int co = t / Kp, k = t % Kp;
       float v = 0.f;
@@ -66,7 +66,7 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
   __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
-  for (int t = bx * 256 + threadIdx.x; t < n8_f + n8_d + n8_g; t += nbx * 256) {
+  for (int t = bx * (int)blockDim.x + threadIdx.x; t < n8_f + n8_d + n8_g; t += nbx * (int)blockDim.x) {
     float v[8];
     __bf16* dst;
     if (t < n8_f + n8_g) {
@@ -126,7 +126,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
     const int ct = tile / nIT, it = tile - ct * nIT, c0 = ct * RC, i0 = it * RI;
     const int rc = min(RC, Cout - c0), ri = min(RI, Cin - i0);   // ri == RI except for a ragged last tile of a 1-tile dim
     __syncthreads();
-    for (int idx = threadIdx.x; idx < rc * ri * taps; idx += 256) {
+    for (int idx = threadIdx.x; idx < rc * ri * taps; idx += blockDim.x) {
       const int r = idx / (ri * taps), x = idx - r * (ri * taps);
       T[r * RLp + x] = d.w[((long)(c0 + r) * Cin + i0) * taps + x];
     }
@@ -135,7 +135,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
     const int per_tap = ri / 8;                                  // used when the tile does not span all of Cin
     const int nq = (ri == Cin) ? Kp / 8 : taps * per_tap + (i0 == 0 ? (Kp - K) / 8 : 0);
     const int rows = (nCT == 1) ? rows_g : rc;                   // a lone row tile also writes wf's zero rows
-    for (int p = threadIdx.x; p < rows * nq; p += 256) {
+    for (int p = threadIdx.x; p < rows * nq; p += blockDim.x) {
       const int r = p / nq, q = p - r * nq, co = c0 + r;
       int k0;
       if (ri == Cin) k0 = q * 8;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
     if (wd) {
       const int per_tap_d = rc / 8;
       const int nqd = (rc == Cout) ? Kpd / 8 : taps * per_tap_d + (c0 == 0 ? (Kpd - Kd) / 8 : 0);
-      for (int p = threadIdx.x; p < ri * nqd; p += 256) {
+      for (int p = threadIdx.x; p < ri * nqd; p += blockDim.x) {
         const int x = p / nqd, q = p - x * nqd, ci = i0 + x;
         int k0;
         if (rc == Cout) k0 = q * 8;
