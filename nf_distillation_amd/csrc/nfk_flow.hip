@@ -119,6 +119,10 @@ __device__ __forceinline__ void prep_body(PrepDesc d, int want_inverse, float* b
   float* T0 = W + CC;
   float* T1 = T0 + CC;
   float* AUG = T1 + CC;
+  // coupling-net scales first: they depend on nothing, and their loads travel under everything below
+  for (int i = threadIdx.x; i < d.n1; i += blockDim.x) d.es1[i] = expf(d.l1[i]);
+  for (int i = threadIdx.x; i < d.n2; i += blockDim.x) d.es2[i] = expf(d.l2[i]);
+  for (int i = threadIdx.x; i < d.n3; i += blockDim.x) d.es3[i] = expf(3.f * d.l3[i]);
   if (C > 0) {
   if (copy_p && d.perm_kind == PERM_LU) {
     float* Pl = W + 5 * CC;
@@ -141,16 +145,19 @@ __device__ __forceinline__ void prep_body(PrepDesc d, int want_inverse, float* b
   }
   if (threadIdx.x == 0) d.dld[0] = s * (float)d.pixels;
 
-  // forward products.  2-D: z = W y ; 1-D: z = y @ W  (y = (x + b) e^{logs})
+  // forward products.  2-D: z = W y ; 1-D: z = y @ W  (y = (x + b) e^{logs}).  Wf also stays in the work area (T1 is
+  // free by now) so that cf does not wait for a read-back of what this workgroup has just written to memory
   for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
     const int o = idx / C, c = idx % C;
     const float w = d.is_1d ? W[c * C + o] : W[idx];
-    d.Wf[idx] = w * expf(d.an_logs[c]);
+    const float v = w * expf(d.an_logs[c]);
+    d.Wf[idx] = v;
+    T1[idx] = v;
   }
   __syncthreads();
   for (int o = threadIdx.x; o < C; o += blockDim.x) {
     float t = 0.f;
-    for (int c = 0; c < C; ++c) t += d.Wf[o * C + c] * d.an_bias[c];
+    for (int c = 0; c < C; ++c) t += T1[o * C + c] * d.an_bias[c];
     d.cf[o] = t;
   }
   if (want_inverse && d.Wi) {
@@ -163,10 +170,6 @@ __device__ __forceinline__ void prep_body(PrepDesc d, int want_inverse, float* b
     for (int c = threadIdx.x; c < C; c += blockDim.x) d.ci[c] = -d.an_bias[c];
   }
   }  // C > 0
-  // coupling-net scales
-  for (int i = threadIdx.x; i < d.n1; i += blockDim.x) d.es1[i] = expf(d.l1[i]);
-  for (int i = threadIdx.x; i < d.n2; i += blockDim.x) d.es2[i] = expf(d.l2[i]);
-  for (int i = threadIdx.x; i < d.n3; i += blockDim.x) d.es3[i] = expf(3.f * d.l3[i]);
 }
 
 __global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ descs, int want_inverse) {
@@ -195,9 +198,11 @@ __global__ void __launch_bounds__(PR_THREADS) prep_repack_kernel(const PrepDesc*
     else prep_body(d, want_inverse, d.scratch, false, sh);
     return;
   }
-  const int r = b - n_prep, w = r >> 6, bx = r & 63;
-  if (w < n_f32) repack_f32_body(rf32[w], bx, 64);
-  else repack_bf16_body(rbf16[w - n_f32], bx, 64, pf_lds);
+  // a repack workgroup = two 256-thread workers on two tiles of the same weight (half the LDS each): with 60 KiB per
+  // workgroup only two fit a CU, and a tile is a chain of three memory round trips -- this halves the number of chains
+  const int r = b - n_prep, w = r >> 5, half = threadIdx.x >> 8, bx = (r & 31) * 2 + half, tid = threadIdx.x & 255;
+  if (w < n_f32) repack_f32_body(rf32[w], bx, 64, tid, 256);
+  else repack_bf16_body(rbf16[w - n_f32], bx, 64, pf_lds + half * RP_LDS_FLOATS, tid, 256);
 }
 
 // In-place reduction of the per-workgroup partial (gWf, gcf) slabs of every step into slab 0:
@@ -216,13 +221,38 @@ __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __rest
 
 // W = P L U: chain a gradient GW (indexed like W) to (lower, upper, log_s); Gs is added to every g_log_s (the log-det
 // term).  T0, T1, T2, Wk: C*C scratch matrices (T0 / T1 are overwritten with L / U).  Block-wide; accumulates.
+// pre (optional): this thread's elements idx = threadIdx.x + e * blockDim.x of `lower`, `upper` and of the diagonal
+// s = sign_s * exp(log_s), loaded by the caller at the start of the kernel (LU_PF per array; only when C*C fits)
+constexpr int LU_PF = 9;
+struct LuPre { float lo[LU_PF], up[LU_PF], sd[LU_PF]; };
+__device__ __forceinline__ void lu_preload(const PrepDesc& d, int C, LuPre& pre) {
+#pragma unroll
+  for (int e = 0; e < LU_PF; ++e) {
+    const int idx = min((int)(threadIdx.x + e * blockDim.x), C * C - 1), i = idx / C;
+    pre.lo[e] = d.lower[idx];
+    pre.up[e] = d.upper[idx];
+    pre.sd[e] = d.sign_s[i] * expf(d.log_s[i]);
+  }
+}
 __device__ __forceinline__ void prep_lu_chain(const PrepDesc& d, const PrepGrad& g, int C, const float* P, const float* GW, float* Wk,
-                              float* T0, float* T1, float* T2, float Gs) {
+                              float* T0, float* T1, float* T2, float Gs, const LuPre* pre = nullptr) {
   const int CC = C * C;
-  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
-    const int i = idx / C, j = idx % C;
-    T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
-    T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
+  if (pre) {
+#pragma unroll
+    for (int e = 0; e < LU_PF; ++e) {
+      const int idx = threadIdx.x + e * blockDim.x;
+      if (idx < CC) {
+        const int i = idx / C, j = idx % C;
+        T0[idx] = i > j ? pre->lo[e] : (i == j ? 1.f : 0.f);
+        T1[idx] = i < j ? pre->up[e] : (i == j ? pre->sd[e] : 0.f);
+      }
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+      const int i = idx / C, j = idx % C;
+      T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
+      T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
+    }
   }
   __syncthreads();
   blk_matmul(P, 1, GW, 0, T2, C);     // T2 = P^T gW
@@ -258,6 +288,13 @@ __device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad&
     for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) Pl[idx] = d.p[idx];   // visible after the first barrier below
   }
 
+  // everything the chain below reads from memory is requested here, before the first wait: the L / U / s elements into
+  // registers, Wf into the W work matrix (free until the LU chain writes it)
+  LuPre pre;
+  const bool use_pre = d.perm_kind == PERM_LU && CC <= LU_PF * (int)blockDim.x;
+  if (use_pre) lu_preload(d, C, pre);
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) W[idx] = d.Wf[idx];
+
   float G = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) G += gld[b];
   G = block_sum(G, sh) * (float)d.pixels;
@@ -271,7 +308,7 @@ __device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad&
   // g_bias[c] = sum_o Wf[o][c] gcf[o];  gWf_tot = gWf + gcf b^T
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float t = 0.f;
-    for (int o = 0; o < C; ++o) t += d.Wf[o * C + c] * T1[o];
+    for (int o = 0; o < C; ++o) t += W[o * C + c] * T1[o];
     g.g_an_bias[c] += t;
   }
   for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) T0[idx] += T1[idx / C] * d.an_bias[idx % C];
@@ -279,7 +316,7 @@ __device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad&
   // g_logs[c] = sum_o gWf_tot[o][c] Wf[o][c] + G ;  gW (in W's own index convention) -> GW
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float t = 0.f;
-    for (int o = 0; o < C; ++o) t += T0[o * C + c] * d.Wf[o * C + c];
+    for (int o = 0; o < C; ++o) t += T0[o * C + c] * W[o * C + c];
     g.g_an_logs[c] += t + G;
   }
   for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
@@ -288,7 +325,7 @@ __device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad&
     if (d.is_1d) GW[c * C + o] = v; else GW[idx] = v;
   }
   __syncthreads();
-  if (d.perm_kind == PERM_LU) prep_lu_chain(d, g, C, P, GW, W, T0, T1, T2, G);
+  if (d.perm_kind == PERM_LU) prep_lu_chain(d, g, C, P, GW, W, T0, T1, T2, G, use_pre ? &pre : nullptr);
 }
 
 __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restrict__ descs,
@@ -993,8 +1030,9 @@ static inline int sample_threads(int n) { return n >= 1024 ? 1024 : (n > 256 ? (
 
 int launch_prep_repack(const PrepDesc* descs_dev, int nsteps, int want_inverse, const nfk_repack_desc* rf32, int n_f32,
                        const nfk_repack_desc* rbf16, int n_bf16, hipStream_t st) {
-  static_assert(PREP_LDS >= RP_LDS_FLOATS * sizeof(float), "the repack tile lives in the prep launch's LDS");
-  const int grid = nsteps + 64 * (n_f32 + n_bf16);
+  static_assert(PREP_LDS >= 2 * RP_LDS_FLOATS * sizeof(float), "two repack tiles live in the prep launch's LDS");
+  static_assert(PR_THREADS == 512, "a repack workgroup is two 256-thread workers");
+  const int grid = nsteps + 32 * (n_f32 + n_bf16);
   if (grid <= 0) return NFK_OK;
   static bool attr = false;
   if (!attr) {

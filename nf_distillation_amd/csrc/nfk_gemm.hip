@@ -495,7 +495,7 @@ __global__ void repack_kernel(const float* __restrict__ W, int Cout, int Cin, in
 }
 
 __global__ void __launch_bounds__(256) repack_batch_kernel(const nfk_repack_desc* __restrict__ descs) {
-  repack_f32_body(descs[blockIdx.y], blockIdx.x, gridDim.x);
+  repack_f32_body(descs[blockIdx.y], blockIdx.x, gridDim.x, threadIdx.x, 256);
 }
 
 // wgrad finalize: gradW[co][ci][tap] += sum_slabs out[s][co][tap*Cin + ci]   (fixed order)

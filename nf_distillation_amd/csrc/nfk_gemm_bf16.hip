@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvGemmArgs a) {
 
 __global__ void __launch_bounds__(256) repack_batch_bf16_kernel(const nfk_repack_desc* __restrict__ descs) {
   __shared__ float T[RP_LDS_FLOATS];
-  repack_bf16_body(descs[blockIdx.y], blockIdx.x, gridDim.x, T);
+  repack_bf16_body(descs[blockIdx.y], blockIdx.x, gridDim.x, T, threadIdx.x, 256);
 }
 
 template <int TN, int TM, int WN, int WM>

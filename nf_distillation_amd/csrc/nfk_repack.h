@@ -16,10 +16,13 @@ __device__ __forceinline__ unsigned rp_pack2(float lo, float hi) {
 }
 
 // f32: W[co][ci][taps] -> wt[co][tap*Cin + ci] (zero padded to Kp) and wd[ci][tap'*Cout + co] (taps flipped)
-__device__ __forceinline__ void repack_f32_body(const nfk_repack_desc& d, const int bx, const int nbx) {
+// (bx, nbx): this worker's index among the workers of the weight; (tid, nthr): the thread's index among the worker's
+// threads -- a worker is a workgroup, or one 256-thread half of a wider one (prep_repack_kernel)
+__device__ __forceinline__ void repack_f32_body(const nfk_repack_desc& d, const int bx, const int nbx, const int tid,
+                                                const int nthr) {
   const int Kp = (d.taps * d.Cin + RP_BK - 1) / RP_BK * RP_BK, Kpd = (d.taps * d.Cout + RP_BK - 1) / RP_BK * RP_BK;
   const long total_f = (long)d.Cout * Kp, total_d = d.wd ? (long)d.Cin * Kpd : 0;
-  for (long t = bx * (long)blockDim.x + threadIdx.x; t < total_f + total_d; t += nbx * (long)blockDim.x) {
+  for (long t = bx * (long)nthr + tid; t < total_f + total_d; t += nbx * (long)nthr) {
     if (t < total_f) {
       const int co = t / Kp, k = t % Kp;
       float v = 0.f;
@@ -56,7 +59,8 @@ __device__ __forceinline__ RepackTiling repack_tiling(int Cout, int Cin, int tap
   return t;
 }
 
-__device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, const int bx, const int nbx) {
+__device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, const int bx, const int nbx, const int tid,
+                                                   const int nthr) {
   // one thread = 8 consecutive output elements (one 16-byte store); 32-bit index math, one division per 8 elements
   const int K = d.taps * d.Cin, Kd = d.taps * d.Cout;
   const int Kp = (K + RP_BKH - 1) / RP_BKH * RP_BKH, Kpd = (Kd + RP_BKH - 1) / RP_BKH * RP_BKH;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
   __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
-  for (int t = bx * (int)blockDim.x + threadIdx.x; t < n8_f + n8_d + n8_g; t += nbx * (int)blockDim.x) {
+  for (int t = bx * nthr + tid; t < n8_f + n8_d + n8_g; t += nbx * nthr) {
     float v[8];
     __bf16* dst;
     if (t < n8_f + n8_g) {
@@ -110,7 +114,7 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
 }
 
 __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, const RepackTiling tl, const int bx, const int nbx,
-                                                  float* T) {
+                                                  float* T, const int tid, const int nthr) {
   const int Cout = d.Cout, Cin = d.Cin, taps = d.taps, RC = tl.RC, RI = tl.RI;
   const int K = taps * Cin, Kd = taps * Cout;
   const int Kp = (K + RP_BKH - 1) / RP_BKH * RP_BKH, Kpd = (Kd + RP_BKH - 1) / RP_BKH * RP_BKH;
@@ -122,11 +126,15 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
   const unsigned mCin = 0xFFFFFFFFu / (unsigned)Cin + 1u, mCout = 0xFFFFFFFFu / (unsigned)Cout + 1u;   // n / C for n < 2^16
-  for (int tile = bx; tile < nCT * nIT; tile += nbx) {
+  // the trip count is the same for every worker of the weight (barriers are workgroup-wide, and a workgroup may hold
+  // two workers): a worker without a tile in the last trip runs it with an empty tile
+  for (int tile0 = 0; tile0 < nCT * nIT; tile0 += nbx) {
+    const int tile = tile0 + bx;
+    const bool live = tile < nCT * nIT;
     const int ct = tile / nIT, it = tile - ct * nIT, c0 = ct * RC, i0 = it * RI;
-    const int rc = min(RC, Cout - c0), ri = min(RI, Cin - i0);   // ri == RI except for a ragged last tile of a 1-tile dim
+    const int rc = live ? min(RC, Cout - c0) : 0, ri = live ? min(RI, Cin - i0) : 0;   // ragged last tiles
     __syncthreads();
-    for (int idx = threadIdx.x; idx < rc * ri * taps; idx += blockDim.x) {
+    for (int idx = tid; idx < rc * ri * taps; idx += nthr) {
       const int r = idx / (ri * taps), x = idx - r * (ri * taps);
       T[r * RLp + x] = d.w[((long)(c0 + r) * Cin + i0) * taps + x];
     }
@@ -134,8 +142,8 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
     // ---- wt / wf: rows of this tile, k-pieces of 8 whose input channels lie in [i0, i0 + ri)
     const int per_tap = ri / 8;                                  // used when the tile does not span all of Cin
     const int nq = (ri == Cin) ? Kp / 8 : taps * per_tap + (i0 == 0 ? (Kp - K) / 8 : 0);
-    const int rows = (nCT == 1) ? rows_g : rc;                   // a lone row tile also writes wf's zero rows
-    for (int p = threadIdx.x; p < rows * nq; p += blockDim.x) {
+    const int rows = !live ? 0 : ((nCT == 1) ? rows_g : rc);     // a lone row tile also writes wf's zero rows
+    for (int p = tid; p < rows * nq; p += nthr) {
       const int r = p / nq, q = p - r * nq, co = c0 + r;
       int k0;
       if (ri == Cin) k0 = q * 8;
@@ -161,7 +169,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
     if (wd) {
       const int per_tap_d = rc / 8;
       const int nqd = (rc == Cout) ? Kpd / 8 : taps * per_tap_d + (c0 == 0 ? (Kpd - Kd) / 8 : 0);
-      for (int p = threadIdx.x; p < ri * nqd; p += blockDim.x) {
+      for (int p = tid; p < ri * nqd; p += nthr) {
         const int x = p / nqd, q = p - x * nqd, ci = i0 + x;
         int k0;
         if (rc == Cout) k0 = q * 8;
@@ -182,12 +190,13 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
 }
 
 // one workgroup's share of one conv weight; T: RP_LDS_FLOATS floats of LDS
-__device__ __forceinline__ void repack_bf16_body(const nfk_repack_desc& d, const int bx, const int nbx, float* T) {
+__device__ __forceinline__ void repack_bf16_body(const nfk_repack_desc& d, const int bx, const int nbx, float* T,
+                                                 const int tid, const int nthr) {
   const RepackTiling tl = repack_tiling(d.Cout, d.Cin, d.taps);
   // (several row tiles cannot write the zero rows a 16-row fragment layout keeps behind Cout)
   const bool ragged_wf = d.wf && d.frag == 2 && (d.Cout & 15) && tl.RC != d.Cout;
-  if (tl.ok && !ragged_wf) repack_tiles_bf16(d, tl, bx, nbx, T);
-  else repack_gather_bf16(d, bx, nbx);
+  if (tl.ok && !ragged_wf) repack_tiles_bf16(d, tl, bx, nbx, T, tid, nthr);
+  else repack_gather_bf16(d, bx, nbx, tid, nthr);
 }
 
 }  // namespace nfk

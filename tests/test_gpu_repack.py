@@ -36,7 +36,10 @@ def _expected(w, frag, Kp, Kpd):
     return wt, wd, wf
 
 
-def test_repack_bf16_layouts():
+@pytest.mark.parametrize("entry", ["nfk_repack_batch_bf16", "nfk_prep_repack"])
+def test_repack_bf16_layouts(entry):
+    """`nfk_prep_repack` runs the same repack bodies inside the launch that also prepares the steps (two 256-thread
+    workers per workgroup there); called here with no steps and no f32 weights."""
     from nf_distillation_amd import capi
     lib = capi.lib()
     dev = torch.device("cuda", 0)
@@ -58,7 +61,10 @@ def test_repack_bf16_layouts():
         keep.append((wdev, wt, wd, wf))
         exp.append((ewt, ewd, ewf))
     dd = capi.struct_array_to_device(descs, dev)
-    capi.check(lib.nfk_repack_batch_bf16(dd.data_ptr(), len(descs), None), "nfk_repack_batch_bf16")
+    if entry == "nfk_repack_batch_bf16":
+        capi.check(lib.nfk_repack_batch_bf16(dd.data_ptr(), len(descs), None), entry)
+    else:
+        capi.check(lib.nfk_prep_repack(None, 0, 0, None, 0, dd.data_ptr(), len(descs), None), entry)
     torch.cuda.synchronize()
     for case, (_, wt, wd, wf), (ewt, ewd, ewf) in zip(CASES, keep, exp):
         assert torch.equal(wt.cpu().view(torch.int16), ewt.reshape(-1).view(torch.int16)), ("wt", case)
