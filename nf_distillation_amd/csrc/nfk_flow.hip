@@ -460,8 +460,10 @@ static inline __host__ __device__ int cm_tile_pixels(int C) {
 // is exactly the g_x this launch produces -- done here per pixel tile instead of in a launch of its own (the tail /
 // channel-mix launch of a step is followed by nothing else).  Its per-column sums become one partial row per
 // workgroup (instead of one per sample), reduced by the same small-gradient code later.
-__device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx, const int nblk,
-                                             const CouplingBwdArgs* nx = nullptr) {
+// (FUSE is a template parameter and `n` a reference to the kernel's own argument: through a pointer to it the argument
+// struct was copied to scratch memory and read back from there)
+template <bool FUSE>
+__device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx, const int nblk, const CouplingBwdArgs& n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C, Cp = (C + 3) & ~3, XS = C + 1, G4 = Cp / 4;
   const int TP = cm_tile_pixels(C);
@@ -470,13 +472,47 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
   float* Gl = Xl + TP * XS;         // [TP][C+1] (backward: x_in tile)
   float* Pl = Gl + TP * XS;         // [C*C + C] (backward: partial sums, each element owned by one thread)
   const int E = C * C + C;
-  const bool fuse = nx != nullptr && nx->ga3 != nullptr;
+  constexpr bool fuse = FUSE;
   const int Chn = C / 2, C2n = C - Chn, Gn = 256 / (C2n > 0 ? C2n : 1);
   float* Ol = Pl + (a.part ? E : 0);      // [TP][C+1] this launch's g_x tile      (fused coupling only)
   float* Al = Ol + TP * XS;               // [Gn][4][C2] per-group column sums     (fused coupling only)
   float* Pc = Al + Gn * 4 * C2n;          // [4][C2] running column sums of this workgroup
   if (fuse)
     for (int idx = threadIdx.x; idx < 4 * C2n; idx += blockDim.x) Pc[idx] = 0.f;
+  const int ntiles = (a.M + TP - 1) / TP;
+  // The workgroup is a chain of memory round trips on very little data (W, the pixel tile, the fused coupling's
+  // operands, the stores): the tile's elements (TP * C <= 1024: at most four per thread) are requested before the
+  // wait for W, and the coupling's operands (below) at the top of the tile instead of after the channel mix.
+  constexpr int XPF = 4;
+  float xv[XPF], gv[XPF];   // the tile about to be processed: loaded one tile ahead
+  auto load_x = [&](int m0) {
+#pragma unroll
+    for (int e = 0; e < XPF; ++e) {
+      const int idx = threadIdx.x + e * 256;
+      const int pp = idx / C, c = idx - pp * C, m = m0 + pp;
+      float v = 0.f, gq = 0.f;
+      // (32-bit element offsets from the arrays' base pointers: one address register per load instead of two; the
+      // tensors of a FlowStep are far below 2^32 elements)
+      if (idx < TP * C && m < a.M) {
+        if (a.ga && c < a.Ch) {
+          v = a.ga[(unsigned)(m * a.lda + c)];
+          if (a.gext) v += a.gext[(unsigned)(m * a.ldge + c)];
+          // conv1's dgrad slabs (one with the halo-tile kernel, a few otherwise), four loads in flight per element:
+          // four elements are loaded side by side here, and slab_sum's sixteen each cost the launch its occupancy
+          const float* sp = a.slab + (unsigned)(m * a.Ch + c);
+          int q = 0;
+          for (; q + 4 <= a.S; q += 4, sp += 4 * a.slab_stride)
+            v += (sp[0] + sp[a.slab_stride]) + (sp[2 * a.slab_stride] + sp[3 * a.slab_stride]);
+          for (; q < a.S; ++q, sp += a.slab_stride) v += sp[0];
+        } else {
+          v = a.x[(unsigned)(m * a.ldx + c)];
+        }
+        if (a.part) gq = a.xin[(unsigned)(m * a.ldxin + c)];
+      }
+      xv[e] = v; gv[e] = gq;
+    }
+  };
+  load_x(bx * TP);   // (a workgroup beyond the last tile loads nothing: every element fails m < M)
   for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
     const int r = idx / C, q = idx - r * C;  // Wm[r][q]
     if (a.trans) Wl[r * Cp + q] = a.Wm[idx];      // in = r (rows of Wm), out = q
@@ -484,26 +520,36 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
   }
   if (a.part)
     for (int idx = threadIdx.x; idx < E; idx += blockDim.x) Pl[idx] = 0.f;
-  const int ntiles = (a.M + TP - 1) / TP;
   const int p = threadIdx.x / G4, og = threadIdx.x - p * G4;
+  // fused coupling: thread (g, j) = column j of pixels g, g + Gn, ... of the tile (at most CPF of them)
+  constexpr int CPF = 4;
+  const int jn = threadIdx.x % C2n, gn = threadIdx.x / C2n;
+  const bool cpl_pre = fuse && (TP + Gn - 1) / Gn <= CPF;
   for (int tile = bx; tile < ntiles; tile += nblk) {
     const int m0 = tile * TP;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < TP * C; idx += blockDim.x) {
-      const int pp = idx / C, c = idx - pp * C, m = m0 + pp;
-      float v = 0.f;
-      if (m < a.M) {
-        if (a.ga && c < a.Ch) {
-          v = a.ga[(long)m * a.lda + c];
-          if (a.gext) v += a.gext[(long)m * a.ldge + c];
-          v += slab_sum(a.slab, a.S, a.slab_stride, (long)m * a.Ch + c);
-        } else {
-          v = a.x[(long)m * a.ldx + c];
-        }
+    float ch0[CPF], ch1[CPF], cz[CPF], cg[CPF];   // next step's h (shift | scale), z2, external gradient
+    if (cpl_pre && gn < Gn) {
+#pragma unroll
+      for (int e = 0; e < CPF; ++e) {
+        const int pp = gn + e * Gn, m = m0 + pp;
+        const bool ok = pp < TP && m < a.M;
+        const unsigned mc = ok ? (unsigned)m : 0u;
+        cg[e] = (ok && n.gext) ? n.gext[mc * n.ldge + Chn + jn] : 0.f;
+        if (n.additive) { ch0[e] = n.h[mc * n.Cout + jn]; ch1[e] = 0.f; cz[e] = 0.f; }
+        else { ch0[e] = n.h[mc * n.Cout + 2 * jn]; ch1[e] = n.h[mc * n.Cout + 2 * jn + 1]; cz[e] = n.z[mc * n.ldz + Chn + jn]; }
       }
-      Xl[pp * XS + c] = v;
-      if (a.part) Gl[pp * XS + c] = m < a.M ? a.xin[(long)m * a.ldxin + c] : 0.f;
     }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < XPF; ++e) {
+      const int idx = threadIdx.x + e * 256;
+      if (idx < TP * C) {
+        const int pp = idx / C, c = idx - pp * C;
+        Xl[pp * XS + c] = xv[e];
+        if (a.part) Gl[pp * XS + c] = gv[e];
+      }
+    }
+    if (tile + nblk < ntiles) load_x((tile + nblk) * TP);   // next tile, under this tile's work
     __syncthreads();
     if (p < TP) {
       const int o = og * 4, m = m0 + p;
@@ -545,33 +591,44 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
     if (fuse) {
       // coupling backward of the next step on this tile (same arithmetic as coupling_bwd_kernel)
       __syncthreads();
-      const CouplingBwdArgs& n = *nx;
       const int j = threadIdx.x % C2n, g = threadIdx.x / C2n;
       float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
       if (g < Gn) {
-        for (int pp = g; pp < TP; pp += Gn) {
-          const long m = (long)m0 + pp;
-          if (m >= a.M) break;
+        // one pixel of this thread's column: operands either preloaded at the top of the tile or read here
+        auto elem = [&](int pp, unsigned m, float hv0, float hv1, float zv, float gv) {
           float g2 = Ol[pp * XS + Chn + j];
-          if (n.gext) g2 += n.gext[m * n.ldge + Chn + j];
+          if (n.gext) g2 += gv;
           if (n.additive) {
-            const float h = n.h[m * n.Cout + j];
             n.gz[m * n.ldgz + Chn + j] = g2;
             const float ga = g2 * n.es3[j];
             n.ga3[m * n.Cout + j] = ga;
-            sb0 += ga; sl0 += g2 * h;
+            sb0 += ga; sl0 += g2 * hv0;
           } else {
             const float gl = n.gld ? n.gld[m / n.HW] : 0.f;
-            const float shf = n.h[m * n.Cout + 2 * j], sr = n.h[m * n.Cout + 2 * j + 1];
+            const float shf = hv0, sr = hv1;
             const float sc = sigmoidf(sr + 2.f);
-            const float z2 = n.z[m * n.ldz + Chn + j];
             const float gshift = g2 * sc;
-            const float gsr = g2 * (z2 + shf) * sc * (1.f - sc) + gl * (1.f - sc);
+            const float gsr = g2 * (zv + shf) * sc * (1.f - sc) + gl * (1.f - sc);
             n.gz[m * n.ldgz + Chn + j] = gshift;
             const float ga0 = gshift * n.es3[2 * j], ga1 = gsr * n.es3[2 * j + 1];
             n.ga3[m * n.Cout + 2 * j] = ga0;
             n.ga3[m * n.Cout + 2 * j + 1] = ga1;
             sb0 += ga0; sl0 += gshift * shf; sb1 += ga1; sl1 += gsr * sr;
+          }
+        };
+        if (cpl_pre) {
+#pragma unroll
+          for (int e = 0; e < CPF; ++e) {
+            const int pp = g + e * Gn, m = m0 + pp;
+            if (pp < TP && m < a.M) elem(pp, (unsigned)m, ch0[e], ch1[e], cz[e], cg[e]);
+          }
+        } else {
+          for (int pp = g; pp < TP; pp += Gn) {
+            const unsigned m = (unsigned)(m0 + pp);
+            if ((int)m >= a.M) break;
+            const float gv = n.gext ? n.gext[m * n.ldge + Chn + j] : 0.f;
+            if (n.additive) elem(pp, m, n.h[m * n.Cout + j], 0.f, 0.f, gv);
+            else elem(pp, m, n.h[m * n.Cout + 2 * j], n.h[m * n.Cout + 2 * j + 1], n.z[m * n.ldz + Chn + j], gv);
           }
         }
         float* row = Al + (long)g * 4 * C2n;
@@ -591,7 +648,6 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
   }
   if (fuse) {
     __syncthreads();
-    const CouplingBwdArgs& n = *nx;
     float* part = n.part + (long)bx * 2 * n.Cout;   // one partial row per workgroup
     for (int jj = threadIdx.x; jj < C2n; jj += blockDim.x) {
       const float t0 = Pc[jj], t1 = Pc[C2n + jj], t2 = Pc[2 * C2n + jj], t3 = Pc[3 * C2n + jj];
@@ -603,7 +659,10 @@ __device__ __forceinline__ void chanmix_body(const ChanMixArgs& a, const int bx,
     }
   }
 }
-__global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) { chanmix_body(a, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) chanmix_kernel(ChanMixArgs a) {
+  const CouplingBwdArgs none{};
+  chanmix_body<false>(a, blockIdx.x, gridDim.x, none);
+}
 
 // ==========================================================================================
 // coupling tail (affine / additive), one workgroup per sample
@@ -1013,8 +1072,10 @@ __global__ void __launch_bounds__(256) step_tail_kernel(SmallGradArgs a, StepTai
 // not queue behind the (many, short) slab-reduction workgroups.
 __global__ void __launch_bounds__(256) tail_chanmix_kernel(SmallGradArgs a, StepTailArgs f, int n_cm, ChanMixArgs m,
                                                            CouplingBwdArgs nx) {
-  if ((int)blockIdx.x < n_cm) chanmix_body(m, blockIdx.x, n_cm, &nx);
-  else step_tail_body(a, f, blockIdx.x - n_cm);
+  if ((int)blockIdx.x < n_cm) {
+    if (nx.ga3) chanmix_body<true>(m, blockIdx.x, n_cm, nx);
+    else chanmix_body<false>(m, blockIdx.x, n_cm, nx);
+  } else step_tail_body(a, f, blockIdx.x - n_cm);
 }
 
 // ==========================================================================================
