@@ -19,7 +19,7 @@ typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int BKH = 64;                 // bf16 elements per k-chunk
 static int g_narrow_halo = 1;            // conv1 dgrad through the halo-tile kernel (nfk_set_tuning(3000 / 3001))
-static int g_wgrad_wide_max_splits = 64;
+static int g_wgrad_wide_max_splits = 32;   // 512x512: 1 MiB per split; 32 = an even 8 chunks per split at CIFAR level 1 (+2.6 % over 48)
 static int g_wgrad_target_wgs = 768, g_wgrad_max_splits = 64;   // nfk_set_tuning(200 + cap) / (1000 + target)
 static int g_big_tile_min_k = 256;      // see big_tiles(); nfk_set_tuning(100 + v) sets it to v*64 (experiments)
 constexpr unsigned OOB = 0x80000000u;
