@@ -447,7 +447,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
   const int nIB = (a.NI + BI - 1) / BI, nJB = (a.J + BJ - 1) / BJ;
   // All tiles of one split read the same pixel range of P and Q: the remap runs over (split, tile) so that they land
   // on ONE XCD and share its L2 (remapping the tiles of each split alone spreads every pixel range over all 8 L2s:
-  // 231 MB of HBM traffic per level-1 conv2 launch against 133 MB algorithmic, profiles/r01_d_pmc_traffic_bf16.json).
+  // 231 MB of HBM traffic per level-1 conv2 launch against 133 MB algorithmic, measured with tools/pmc_traffic.py).
   const int nT = nIB * nJB;
   const int lin = xcd_remap_b(z_in * nT + bx, nT * S);
   const int z = lin / nT, bid = lin - z * nT;
@@ -595,7 +595,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
 // ------------------------------------------------------------------------------------------
 // Narrow 3x3 conv from a WIDE bf16 input (conv1's dgrad: 512 -> C/2 channels) with the input tile in LDS.
 // The implicit-GEMM kernel above fetches every input element once per tap (9x: 151 MB for the 17 MB gradient of a
-// CIFAR level-1 step, profiles/r01_d_pmc_traffic_bf16.json).  Here a workgroup owns 64 consecutive pixels (raster
+// CIFAR level-1 step, measured with tools/pmc_traffic.py).  Here a workgroup owns 64 consecutive pixels (raster
 // order over [B*H*W]); the rows m0 - W - 1 ... m0 + 64 + W of the input are staged once, 128 channels at a time, in a
 // swizzled LDS image (double-buffered), and the 9 taps are shifted row reads of that image.  Taps that fall outside the
 // pixel's image read a 16-byte zero slot instead (lane-constant address select); rows outside [0, M) are zero-filled
