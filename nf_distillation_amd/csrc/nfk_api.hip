@@ -456,13 +456,15 @@ int nfk_split2d_bwd(const nfk_split2d* s, const float* x, const float* hsave, co
   w.P = ga; w.ldp = C; w.NI = C; w.Q = x; w.ldq = C; w.Cq = Ch; w.taps = 9; w.B = B; w.H = H; w.W = W;
   w.out = wslab; w.slab_stride = (long)C * 9 * Ch;
   NFK_TRY(wgrad_gemm(w, Sw, st));
-  NFK_TRY(wgrad_finalize(wslab, Sw, w.slab_stride, C, Ch, 9, g_w, st));
   ConvGemmArgs d = conv_args(ga, C, B, H, W, C, 9, s->wd, Ch, dslab, Ch, EPI_RAW);
   NFK_TRY(conv_gemm(d, st));
   NFK_TRY(launch_add_slabs(g_z1, Ch, g_ext, Ch, dslab, Sd, (long)M * Ch, g_x, C, M, Ch, st));
+  // the weight gradient's slab reduction and the per-channel gradients in one launch (as at the end of a FlowStep)
   nfk_small_grad_args sg{};
   sg.tail = tail; sg.B = B; sg.n3 = C; sg.g_bias3 = g_bias; sg.g_l3 = g_logs;
-  return launch_small_grads(sg, st);
+  StepTailArgs f{};
+  f.slabs[0] = wslab; f.gradW[0] = g_w; f.stride[0] = w.slab_stride; f.S[0] = Sw; f.Cout[0] = C; f.Cin[0] = Ch; f.taps[0] = 9;
+  return launch_step_tail(sg, f, st);
 }
 
 }  // extern "C"
