@@ -216,7 +216,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # HIP events bracket each launch: eager steps (outside the captured graph), on ONE stream, so that a launch's
-        # duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r01_g_*)
+        # duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r01_h_*)
         step.enable_concurrency(False)
         if pipelined:   # both models run their deep-level fused steps with the pipelined schedule's split policy
             teacher.flow.engine().fused_split_inference = runner.teacher_split
@@ -242,12 +242,12 @@ def main():
         traffic, traffic_src = None, None
         sym = {"<*,1,*>": "nfk::fused2_step_fwd_kernel<3, 1, 4, 1>", "<*,2,*>": "nfk::fused2_step_fwd_kernel<2, 2, 8, 4>",
                "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>"}   # levels 2 / 3: the student's instances
-        pmc_file = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic_bf16.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_bf16.json")
         if args.dtype == "bf16" and os.path.exists(pmc_file):
             kern = json.load(open(pmc_file)).get("kernels", {})
             for tag, name in sym.items():
                 if tag in dom["kernel"] and name in kern:
-                    traffic, traffic_src = kern[name]["hbm_bytes_per_launch_corrected"], "profiles/r01_g_pmc_traffic_bf16.json"
+                    traffic, traffic_src = kern[name]["hbm_bytes_per_launch_corrected"], "profiles/r01_h_pmc_traffic_bf16.json"
         result["roofline"] = {
             "bound": "hbm" if hbm_bound else "mfma",
             "kernel": dom["kernel"] + (" [bf16 operands]" if args.dtype == "bf16" else " [f32]"),

@@ -1,4 +1,4 @@
-# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>      e.g. r01_g
+# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>      e.g. r01_h
 # Writes under gpurun_out/: the default bench line, the rocprofv3 kernel stats of the same command (+ its bench line), and
 # the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace only) summarised by tools/pmc_traffic.py.
 set -e
