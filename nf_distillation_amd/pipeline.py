@@ -80,8 +80,7 @@ class PipelinedStep:
         if self.t_next is None:
             self.t_next = [torch.empty_like(h) for h in hints]
             self.t_cur = [torch.empty_like(h) for h in hints]
-        for dst, h in zip(self.t_next, hints):
-            dst.copy_(h)
+        torch._foreach_copy_(self.t_next, hints)   # one launch for all hint tensors
 
     def _student_fwd_bwd(self):
         st = self.step
@@ -101,9 +100,8 @@ class PipelinedStep:
         return {k: v.detach() for k, v in out.items()}
 
     def _handover(self):
-        for dst, src in zip(self.t_cur, self.t_next):
-            dst.copy_(src)
-        self.x_cur.copy_(self.x_stu_next)
+        # one launch (multi-tensor copy) instead of one per tensor: these sit at the head of both chains
+        torch._foreach_copy_(self.t_cur + [self.x_cur], self.t_next + [self.x_stu_next])
 
     def _body_a(self):
         """both branches up to the end of the backward"""
