@@ -362,7 +362,8 @@ def kd_indices(student_cfg, teacher_cfg):
 
 
 def distill_losses(student_z, student_nll, teacher_z, s_idx, t_idx, w_nll, w_kd):
-    """NFModel.loss (pl_module.py:257-320) with perceptual weight 0."""
+    """NFModel.loss (pl_module.py:257-320) with perceptual weight 0.  The hint lists are ZIPPED (the shorter one
+    decides how many pairs there are) while the divisor is len(student_kd_indices) (:264-282)."""
     kd = None
     if w_kd > 0:
         for si, ti in zip(s_idx, t_idx):
@@ -372,7 +373,7 @@ def distill_losses(student_z, student_nll, teacher_z, s_idx, t_idx, w_nll, w_kd)
     else:
         kd = torch.zeros((), dtype=student_nll.dtype)
     res = w_nll * student_nll + w_kd * kd
-    return {"nll": student_nll.mean(), "kd": kd.mean(), "result_loss": res.mean()}
+    return {"nll": student_nll.mean(), "kd": kd.mean(), "result_loss": res.mean(), "per_sample": res}
 
 
 def clip_grad_norm(grads: List[Tensor], max_norm: float) -> Tensor:
@@ -419,29 +420,69 @@ def perceptual_l1(student_sd, student_cfg, teacher_sd, teacher_cfg, latent, y_on
 
 
 def distill_step(student_sd, student_cfg, teacher_sd, teacher_cfg, x, noise_s, noise_t,
-                 opt_state, lr=5e-4, w_nll=0.9, w_kd=0.1, clip=30.0, w_perc=0.0, latent=None):
+                 opt_state, lr=5e-4, w_nll=0.9, w_kd=0.1, clip=30.0, w_perc=0.0, latent=None,
+                 y_onehot=None, weights=None, keep_grads=False):
     """One training step as the reference runs it: student fwd (grad), teacher fwd on the
-    SAME (already noised, in-place) x (no grad), MSE hints, [perceptual branch], clip, Adam on the student.
+    SAME (already noised, in-place) x (no grad), MSE hints, [perceptual branch], [per-sample weights,
+    pl_module.py:309-310], clip, Adam on the student.  `y_onehot` goes to both forwards, the prior and both
+    reverse passes when the student is conditional (pl_module.py:216-243).
     Returns dict of scalars; mutates student_sd and x."""
     names = [k for k in student_sd if not is_buffer(k)]
     for k in names:
         student_sd[k].requires_grad_(True)
         student_sd[k].grad = None
     s_idx, t_idx = kd_indices(student_cfg, teacher_cfg)
-    s_z, s_nll, _ = glow_forward(student_sd, student_cfg, x, None, noise_s)
+    s_z, s_nll, _ = glow_forward(student_sd, student_cfg, x, y_onehot, noise_s)
     with torch.no_grad():
-        t_z, _, _ = glow_forward(teacher_sd, teacher_cfg, x, None, noise_t)
+        t_z, _, _ = glow_forward(teacher_sd, teacher_cfg, x, y_onehot, noise_t)
     out = distill_losses(s_z, s_nll, t_z, s_idx, t_idx, w_nll, w_kd)
+    per_sample = out.pop("per_sample")
     if w_perc > 0:
-        per, _, _ = perceptual_l1(student_sd, student_cfg, teacher_sd, teacher_cfg, latent)
+        per, _, _ = perceptual_l1(student_sd, student_cfg, teacher_sd, teacher_cfg, latent, y_onehot)
         out["perceptual"] = per.mean()
-        out["result_loss"] = out["result_loss"] + w_perc * per.mean()   # mean_b of a sum = sum of the means
+        per_sample = per_sample + w_perc * per
+    if weights is not None:
+        per_sample = per_sample * weights
+    out["result_loss"] = per_sample.mean()
     out["result_loss"].backward()
     with torch.no_grad():
         params = [student_sd[k] for k in names]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
         out["grad_norm"] = clip_grad_norm(grads, clip)
+        if keep_grads:
+            out["grads"] = {k: g.clone() for k, g in zip(names, grads)}
         for p in params:
             p.requires_grad_(False)
         adam_step(params, grads, opt_state, lr)
     return {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in out.items()}
+
+
+# --------------------------------------------------------------------------------------
+# permutation inheritance (models/kd_flows.py:162-179) and the image pipeline (data/src/utils.py:7-25)
+# --------------------------------------------------------------------------------------
+def inherit_permutation_matrix(student_sd, teacher_sd, teacher_cfg, s_idx, t_idx):
+    """models/kd_flows.py:162-179: at every teacher hint layer the student's hint layer gets
+    p = (product of the teacher's p since the previous hint layer) @ (the hint layer's p).
+    With nothing accumulated the reference computes `None @ p` -> TypeError; kept."""
+    k, acc = 0, None
+    for t_id, (kind, _) in enumerate(layer_schedule(teacher_cfg)):
+        p = teacher_sd.get(f"flow.layers.{t_id}.invconv.p")
+        if t_id == t_idx[k]:
+            if acc is None:
+                raise TypeError("unsupported operand type(s) for @: 'NoneType' and 'Tensor'")
+            student_sd[f"flow.layers.{s_idx[k]}.invconv.p"] = acc @ p
+            k += 1
+            acc = None
+        elif kind == "step":
+            acc = p if acc is None else acc @ p
+
+
+def preprocess(x):
+    """data/src/utils.py:7-18 with n_bits = 8: x in [0,1] (ToTensor) -> x*255/256 - 0.5."""
+    return x * 255 / 256 - 0.5
+
+
+def postprocess(x):
+    """data/src/utils.py:21-25."""
+    x = torch.clamp(x, -0.5, 0.5) + 0.5
+    return torch.clamp(x * 255, 0, 255).byte()

@@ -26,6 +26,7 @@ import torch
 warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+from golden_util import tensor_digest  # noqa: E402
 from param_util import randomize_state_dict, shapes_of, synthetic_images  # noqa: E402
 
 REF = "/root/reference/models"
@@ -183,8 +184,8 @@ def primitive_case():
         c = shape[1]
         an = (layers.ActNorm1d if is_1d else layers.ActNorm2d)(c)
         an.inited = True
-        an.bias.data = torch.randn_like(an.bias) * 0.3
-        an.logs.data = torch.randn_like(an.logs) * 0.3
+        an.bias.data = torch.randn(an.bias.shape, generator=g) * 0.3   # seeded: the fixture is reproducible
+        an.logs.data = torch.randn(an.logs.shape, generator=g) * 0.3
         xx = torch.randn(*shape, generator=g)
         ld = torch.randn(shape[0], generator=g)
         y, ldo = an(xx, ld, reverse=False)
@@ -357,8 +358,226 @@ def reverse_grad_cases():
                                                     y_condition=True, learn_top=True), 8, 124)
 
 
+# ------------------------------------------------------------------------------------------------
+# round 2: full-size gradients / full-size distillation step, permutation inheritance, image pipeline,
+# the RICH-style conditional distillation step with unequal hint lists
+# ------------------------------------------------------------------------------------------------
+def full_grads_case(name, cfg, batch, seed):
+    """Full-size model (hidden 512): bpd.mean().backward() on the reference; parameters are rebuilt by the tests
+    from (shapes, seed); stored: bpd and a digest of every parameter gradient."""
+    model, _ = build(cfg, seed)
+    model.train()
+    h, w, c = cfg["image_shape"]
+    x, noise = synthetic_images(batch, (c, h, w), seed=seed + 5)
+    xin = (x + noise).clone()
+    ld0 = torch.full((batch,), -math.log(256.0) * c * h * w)
+    outs, obj = model.flow(xin, y_onehot=None, logdet=ld0, reverse=False)
+    mean, logs = model.prior(xin, None)
+    obj = obj + layers.gaussian_likelihood(mean, logs, outs[-1])
+    bpd = -obj / (math.log(2.0) * c * h * w)
+    bpd.mean().backward()
+    named = [(k, p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()]
+    arrays = {"bpd": bpd, "seed": np.array(seed), "batch": np.array(batch),
+              "n_params": np.array(len(named))}
+    tensor_digest(arrays, "grad/", named)
+    save(name, cfg, arrays)
+
+
+def distill_full_case():
+    """Two optimisation steps of the CIFAR distillation step at FULL size (teacher K=32 -> student K=8, hidden 512,
+    B=4): pl_module.py:198-320 + :350-354 + train.py:46 on the reference's models, as distill_case does on toys.
+    Parameters are rebuilt by the tests from (shapes, seed) -- bench.py's seeds 11 / 12."""
+    cifar = dict(image_shape=[32, 32, 3], hidden_channels=512, L=3)
+    s_cfg, t_cfg = base_cfg(K=8, **cifar), base_cfg(K=32, **cifar)
+    student, _ = build(s_cfg, 11)
+    teacher, _ = build(t_cfg, 12)
+    teacher.eval()
+    pick = lambda m: [i for i, l in enumerate(m.flow.layers)
+                      if isinstance(l, layers.SqueezeLayer) or i + 1 == len(m.flow.layers)]
+    s_idx, t_idx = pick(student), pick(teacher)
+    opt = torch.optim.Adam(student.parameters(), lr=5e-4, weight_decay=0)
+    arrays = {"s_idx": np.array(s_idx), "t_idx": np.array(t_idx), "s_seed": np.array(11), "t_seed": np.array(12),
+              "batch": np.array(4)}
+    for step in range(2):
+        x, _ = synthetic_images(4, (3, 32, 32), seed=300 + step)
+        g = torch.Generator().manual_seed(310 + step)
+        n_s = torch.rand(x.shape, generator=g) / 256.0
+        n_t = torch.rand(x.shape, generator=g) / 256.0
+        arrays[f"step{step}/noise_seed"] = np.array(310 + step)
+        opt.zero_grad()
+        # explicit noise (the reference's own draw is replayed bit-exactly in distill_case; here the dequantised
+        # input goes straight into .flow, exactly what normal_flow does after uniform_binning_correction)
+        ld0 = torch.full((4,), -math.log(256.0) * 3 * 32 * 32)
+        xs = x + n_s
+        s_z, obj = student.flow(xs, y_onehot=None, logdet=ld0.clone(), reverse=False)
+        mean, logs = student.prior(xs, None)
+        obj = obj + layers.gaussian_likelihood(mean, logs, s_z[-1])
+        s_nll = -obj / (math.log(2.0) * 3 * 32 * 32)
+        with torch.no_grad():
+            t_z, _ = teacher.flow(xs + n_t, y_onehot=None, logdet=ld0.clone(), reverse=False)
+        kd_val = None
+        for si, ti in zip(s_idx, t_idx):
+            d = torch.nn.functional.mse_loss(s_z[si], t_z[ti], reduction="none")
+            d = d.mean(dim=list(range(d.dim()))[1:])
+            kd_val = d if kd_val is None else kd_val + d
+        kd_val = kd_val / len(s_idx)
+        res = (0.9 * s_nll + 0.1 * kd_val).mean()
+        res.backward()
+        gn = torch.nn.utils.clip_grad_norm_(student.parameters(), 30.0)
+        tensor_digest(arrays, f"step{step}/grad/", [(k, p.grad) for k, p in student.named_parameters()])
+        opt.step()
+        arrays[f"step{step}/nll"], arrays[f"step{step}/kd"] = s_nll.mean(), kd_val.mean()
+        arrays[f"step{step}/loss"], arrays[f"step{step}/grad_norm"] = res, gn
+        arrays[f"step{step}/bpd"] = s_nll
+        tensor_digest(arrays, f"step{step}/after/", list(student.named_parameters()))
+    save("distill_full", {"student": s_cfg, "teacher": t_cfg}, arrays)
+
+
+def inherit_case():
+    """inherit_permutation_matrix (models/kd_flows.py:162-179, called at pl_module.py:71) on 1-D flows.
+    Working geometry: teacher K=8 / student K=4 (hint layers [3,7] / [1,3]: FlowSteps lie between consecutive
+    teacher hint layers and the last hint is the last layer).  Also recorded: what the reference does for
+    K=5 / K=3 with [3,4] / [1,2] (adjacent hint layers -> `None @ p`)."""
+    tab = dict(L=1, is_1d=True, y_classes=0, image_shape=[6])
+    s_cfg, t_cfg = base_cfg(K=4, **tab), base_cfg(K=8, **tab)
+    student, s_sd = build(s_cfg, 131)
+    teacher, t_sd = build(t_cfg, 133)
+    s_idx, t_idx = [1, 3], [3, 7]
+    kd.inherit_permutation_matrix(student, teacher, s_idx, t_idx)
+    arrays = {f"s_sd/{k}": v for k, v in s_sd.items()}
+    arrays.update({f"t_sd/{k}": v for k, v in t_sd.items()})
+    arrays["s_idx"], arrays["t_idx"] = np.array(s_idx), np.array(t_idx)
+    for i in s_idx:
+        arrays[f"p_after/{i}"] = student.flow.layers[i].invconv.p.clone()
+    g = torch.Generator().manual_seed(135)
+    x = torch.randn(8, 6, generator=g)
+    arrays["x"] = x.clone()
+    with torch.no_grad():
+        outs, bpd, _ = student(x, None)
+    arrays["bpd"] = bpd
+    arrays["last"] = outs[-1]
+    # the adjacent-hint geometry the tabular K=3 <- K=5 pair has
+    s2, _ = build(base_cfg(K=3, **tab), 137)
+    t2, _ = build(base_cfg(K=5, **tab), 139)
+    try:
+        kd.inherit_permutation_matrix(s2, t2, [1, 2], [3, 4])
+        err = "none"
+    except Exception as exc:  # noqa: BLE001
+        err = type(exc).__name__
+    arrays["adjacent_error"] = np.frombuffer(err.encode(), dtype=np.uint8)
+    save("inherit_perm", {"student": s_cfg, "teacher": t_cfg}, arrays)
+
+
+def image_pipeline_case():
+    """data/src/utils.py:7-25 (`preprocess`, `postprocess`), imported from the reference file (it needs only torch).
+    torchvision is absent, so ToTensor's `uint8 HWC -> float CHW / 255` in front of preprocess and
+    RandomHorizontalFlip's mirror are written out here (data/src/cifar10.py:14-25 composes them in that order)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_utils", "/root/reference/data/src/utils.py")
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    g = torch.Generator().manual_seed(141)
+    arrays = {}
+    allv = torch.arange(256, dtype=torch.uint8).view(1, 16, 16, 1)
+    u = torch.randint(0, 256, (6, 32, 32, 3), dtype=torch.uint8, generator=g)
+    flip = torch.rand(6, generator=g) < 0.5
+    to_tensor = lambda t: t.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    arrays["all/u8"], arrays["all/x"] = allv, du.preprocess(to_tensor(allv))
+    arrays["rand/u8"], arrays["rand/flip"] = u, flip
+    arrays["rand/x"] = du.preprocess(to_tensor(u))
+    uf = torch.where(flip.view(-1, 1, 1, 1), u.flip(2), u)       # mirror W of the HWC image, before ToTensor
+    arrays["rand/x_flipped"] = du.preprocess(to_tensor(uf))
+    x = torch.randn(5, 3, 16, 16, generator=g) * 0.4
+    x[0, 0, 0, :8] = torch.tensor([-0.5, 0.5, -0.50001, 0.49999, 0.0, 1e9, -1e9, 0.5 - 1.0 / 512])
+    x[0, 0, 1, :2] = torch.tensor([float("inf"), float("-inf")])
+    arrays["post/x"] = x.clone()
+    arrays["post/u8"] = du.postprocess(x.clone())                # [B,C,H,W] uint8
+    save("image_pipeline", {}, arrays)
+
+
+def distill_rich_case():
+    """The RICH recipe in miniature (conf/{teacher,student,training}/rich.yaml): conditional 1-D flows (y_condition,
+    3 condition features... y_classes=3), student K=8 L=2 / teacher K=8 L=3 -> EIGHT student hint layers against SIX teacher hint
+    layers (pl_module.py:81-110; loss() zips them and divides by len(student_kd_indices), :262-282), loss weights
+    0.85 / 0.075 (mse) / 0.075 (l1), per-sample `weights` multiplied into the loss (:309-310), y passed to student,
+    teacher, prior and both reverse passes (:216-243).  Two steps, clip 30 + Adam."""
+    tab = dict(is_1d=True, image_shape=[5], y_classes=3, y_condition=True, learn_top=False)
+    s_cfg = base_cfg(K=8, L=2, hidden_channels=32, **tab)
+    t_cfg = base_cfg(K=8, L=3, hidden_channels=64, **tab)
+    student, s_sd = build(s_cfg, 151)
+    teacher, t_sd = build(t_cfg, 153)
+    teacher.eval()
+    s_idx = [i for i in range(16) if (i + 1) % 2 == 0 or i + 1 == 16]
+    t_idx = [i for i in range(24) if (i + 1) % 4 == 0 or i + 1 == 24]
+    assert len(s_idx) == 8 and len(t_idx) == 6
+    opt = torch.optim.Adam(student.parameters(), lr=5e-4, weight_decay=0)
+    # parameters are rebuilt by the tests from (state_dict shapes, seed)
+    arrays = {"s_seed": np.array(151), "t_seed": np.array(153)}
+    arrays["s_idx"], arrays["t_idx"] = np.array(s_idx), np.array(t_idx)
+    l1 = torch.nn.L1Loss(reduction="none")
+    for step in range(2):
+        g = torch.Generator().manual_seed(160 + step)
+        B = 16
+        x = torch.randn(B, 5, generator=g)
+        y = torch.randn(B, 3, generator=g)          # RICH conditions on 3 real-valued features, not on a one-hot
+        wts = torch.rand(B, generator=g) + 0.5
+        arrays[f"step{step}/x"], arrays[f"step{step}/y"], arrays[f"step{step}/weights"] = x.clone(), y, wts
+        opt.zero_grad()
+        s_z, s_nll, _ = student(x, y)
+        with torch.no_grad():
+            t_z, _, _ = teacher(x, y)
+        kd_val = None
+        for si, ti in zip(s_idx, t_idx):
+            d = torch.nn.functional.mse_loss(s_z[si], t_z[ti], reduction="none")
+            d = d.mean(dim=list(range(d.dim()))[1:])
+            kd_val = d if kd_val is None else kd_val + d
+        kd_val = kd_val / len(s_idx)
+        mean, logs = student.prior(x, y_onehot=y)
+        torch.manual_seed(170 + step)
+        latent = layers.gaussian_sample(mean, logs, 1)
+        arrays[f"step{step}/latent"] = latent.clone()
+        student_x = student(z=latent, temperature=0.7, reverse=True, y_onehot=y)[-1]
+        with torch.no_grad():
+            teacher_x = teacher(z=latent, temperature=0.7, reverse=True, y_onehot=y)[-1]
+        perc = l1(student_x, teacher_x)
+        perc = perc.mean(dim=list(range(perc.dim()))[1:])
+        perc[(torch.isnan(perc)).nonzero(as_tuple=True)[0]] = 0
+        res = 0.85 * s_nll + 0.075 * kd_val + 0.075 * perc
+        res = res * wts
+        res = res.mean()
+        res.backward()
+        gn = torch.nn.utils.clip_grad_norm_(student.parameters(), 30.0)
+        for k, p in student.named_parameters():
+            arrays[f"step{step}/grad/{k}"] = p.grad.clone() if p.grad is not None else torch.zeros_like(p)
+        opt.step()
+        arrays[f"step{step}/nll"], arrays[f"step{step}/kd"] = s_nll.mean(), kd_val.mean()
+        arrays[f"step{step}/perceptual"], arrays[f"step{step}/loss"] = perc.mean(), res
+        arrays[f"step{step}/grad_norm"] = gn
+        for k, v in student.state_dict().items():
+            arrays[f"step{step}/s_sd_after/{k}"] = v.clone()
+    save("distill_rich5", {"student": s_cfg, "teacher": t_cfg}, arrays)
+
+
+def round2_cases():
+    primitive_case()     # now seeded end to end
+    cifar = dict(image_shape=[32, 32, 3], hidden_channels=512, L=3)
+    full_grads_case("cifar_k8_full_grads", base_cfg(K=8, **cifar), 4, 201)
+    distill_full_case()
+    inherit_case()
+    image_pipeline_case()
+    distill_rich_case()
+    full_grads_case("celeba_l4_k32_full_grads",
+                    base_cfg(image_shape=[64, 64, 3], hidden_channels=512, K=32, L=4), 2, 203)
+    # CelebA student geometry of the reference (conf/student/celeba.yaml: K=16, hidden 256, L=3) at 64x64
+    full_grads_case("celeba_student_k16_h256_grads",
+                    base_cfg(image_shape=[64, 64, 3], hidden_channels=256, K=16, L=3), 2, 205)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--round2" in sys.argv:   # added in round 2: leaves the earlier fixtures (except primitives) untouched
+        round2_cases()
+        sys.exit(0)
     if "--only-reverse-grad" in sys.argv:   # added after the other fixtures were committed: leaves them untouched
         reverse_grad_cases()
         distill_tab_case()

@@ -230,3 +230,112 @@ def test_tabular_distillation_step_with_perceptual_branch():
         assert rel_err(res["grad_norm"], g.t(p + "grad_norm")) < 1e-4
         for k, ref in g.group(p + "s_sd_after").items():
             assert float((s_sd[k] - ref).abs().max()) < 2e-5, k
+
+
+# ------------------------------------------------------------------------------------------------ round 2 fixtures
+def _model_shapes(cfg):
+    """state_dict key -> shape of a model built by the product's module tree (CPU, no kernels); its keys / shapes are
+    checked against the reference's in tests/test_checkpoint.py."""
+    import nf_distillation_amd as nfa
+    return {k: tuple(v.shape) for k, v in nfa.create_glow_model(dict(cfg)).state_dict().items()}
+
+
+@pytest.mark.parametrize("name", ["cifar_k8_full_grads", "celeba_student_k16_h256_grads", "celeba_l4_k32_full_grads"])
+def test_full_size_gradients(name):
+    """bpd.mean().backward() at hidden 512 / 256: the oracle's autograd against digests of the reference's gradients."""
+    from golden_util import digest_errors
+    g = Golden(name)
+    cfg = g.cfg
+    sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+    names = [k for k in sd if not O.is_buffer(k)]
+    for k in names:
+        sd[k].requires_grad_(True)
+    h, w, c = cfg["image_shape"]
+    x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 5)
+    _, bpd, _ = O.glow_forward(sd, cfg, x, None, noise)
+    assert rel_err(bpd, g.t("bpd")) < 2e-6
+    bpd.mean().backward()
+    named = [(k, sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in names]
+    assert len(named) == int(g.t("n_params"))
+    for k, e_abs, e_smp, e_sum in digest_errors(g, "grad/", named):
+        assert e_abs < 1e-4 and e_smp < 1e-3 and e_sum < 1e-4, (k, e_abs, e_smp, e_sum)
+
+
+def test_full_size_distillation_step():
+    """Teacher K=32 -> student K=8 at hidden 512, B=4, two steps: losses, clipped gradients, parameters after Adam."""
+    from golden_util import digest_errors
+    g = Golden("distill_full")
+    s_cfg, t_cfg = g.cfg["student"], g.cfg["teacher"]
+    s_sd = randomize_state_dict(full_shapes(s_cfg), int(g.t("s_seed")))
+    t_sd = randomize_state_dict(full_shapes(t_cfg), int(g.t("t_seed")))
+    assert O.kd_indices(s_cfg, t_cfg) == (g.t("s_idx").tolist(), g.t("t_idx").tolist())
+    names = [k for k in s_sd if not O.is_buffer(k)]
+    state = {}
+    for step in range(2):
+        p = f"step{step}/"
+        x, _ = synthetic_images(4, (3, 32, 32), seed=300 + step)
+        gen = torch.Generator().manual_seed(int(g.t(p + "noise_seed")))
+        n_s = torch.rand(x.shape, generator=gen) / 256.0
+        n_t = torch.rand(x.shape, generator=gen) / 256.0
+        res = O.distill_step(s_sd, s_cfg, t_sd, t_cfg, x, n_s, n_t, state, keep_grads=True)
+        assert rel_err(res["nll"], g.t(p + "nll")) < 2e-6
+        assert rel_err(res["kd"], g.t(p + "kd")) < 1e-4
+        assert rel_err(res["result_loss"], g.t(p + "loss")) < 2e-6
+        assert rel_err(res["grad_norm"], g.t(p + "grad_norm")) < 1e-4
+        for k, e_abs, e_smp, e_sum in digest_errors(g, p + "grad/", [(k, res["grads"][k]) for k in names]):
+            assert e_abs < 1e-4 and e_smp < 1e-3 and e_sum < 1e-4, (step, k, e_abs, e_smp, e_sum)
+        for k, e_abs, e_smp, e_sum in digest_errors(g, p + "after/", [(k, s_sd[k]) for k in names]):
+            assert e_abs < 1e-5 and e_sum < 1e-4, (step, k, e_abs, e_sum)
+
+
+def test_inherit_permutation_matrix():
+    g = Golden("inherit_perm")
+    s_sd, t_sd = g.group("s_sd"), g.group("t_sd")
+    s_idx, t_idx = g.t("s_idx").tolist(), g.t("t_idx").tolist()
+    O.inherit_permutation_matrix(s_sd, t_sd, g.cfg["teacher"], s_idx, t_idx)
+    for i in s_idx:
+        assert torch.equal(s_sd[f"flow.layers.{i}.invconv.p"], g.t(f"p_after/{i}"))
+    with torch.no_grad():
+        outs, bpd, _ = O.glow_forward(s_sd, g.cfg["student"], g.t("x").clone())
+    assert rel_err(bpd, g.t("bpd")) < 2e-6 and rel_err(outs[-1], g.t("last")) < 2e-5
+    # adjacent hint layers (the K=3 <- K=5 tabular pair): the reference raises TypeError (`None @ p`)
+    assert bytes(g.arrays["adjacent_error"]).decode() == "TypeError"
+    tab = dict(g.cfg["teacher"], K=5)
+    t5 = randomize_state_dict(_model_shapes(tab), 139)
+    s3 = randomize_state_dict(_model_shapes(dict(g.cfg["student"], K=3)), 137)
+    with pytest.raises(TypeError):
+        O.inherit_permutation_matrix(s3, t5, tab, [1, 2], [3, 4])
+
+
+def test_image_pipeline():
+    g = Golden("image_pipeline")
+    to_tensor = lambda t: t.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    assert torch.equal(O.preprocess(to_tensor(g.t("all/u8"))), g.t("all/x"))
+    assert torch.equal(O.preprocess(to_tensor(g.t("rand/u8"))), g.t("rand/x"))
+    assert torch.equal(O.postprocess(g.t("post/x")), g.t("post/u8"))
+
+
+def test_rich_style_conditional_distillation_step():
+    """Conditional 1-D flows, 8 student hints vs 6 teacher hints (zip, divisor 8), per-sample weights, perceptual branch."""
+    g = Golden("distill_rich5")
+    s_cfg, t_cfg = g.cfg["student"], g.cfg["teacher"]
+    s_sd = randomize_state_dict(_model_shapes(s_cfg), int(g.t("s_seed")))
+    t_sd = randomize_state_dict(_model_shapes(t_cfg), int(g.t("t_seed")))
+    s_idx, t_idx = O.kd_indices(s_cfg, t_cfg)
+    assert (s_idx, t_idx) == (g.t("s_idx").tolist(), g.t("t_idx").tolist()) and len(s_idx) == 8 and len(t_idx) == 6
+    state = {}
+    for step in range(2):
+        p = f"step{step}/"
+        res = O.distill_step(s_sd, s_cfg, t_sd, t_cfg, g.t(p + "x").clone(), None, None, state, w_nll=0.85, w_kd=0.075,
+                             w_perc=0.075, latent=g.t(p + "latent"), y_onehot=g.t(p + "y"), weights=g.t(p + "weights"),
+                             keep_grads=True)
+        assert rel_err(res["nll"], g.t(p + "nll")) < 2e-6
+        assert rel_err(res["kd"], g.t(p + "kd")) < 1e-4
+        assert rel_err(res["perceptual"], g.t(p + "perceptual")) < 1e-5
+        assert rel_err(res["result_loss"], g.t(p + "loss")) < 2e-6
+        assert rel_err(res["grad_norm"], g.t(p + "grad_norm")) < 1e-4
+        for k, ref in g.group(p + "grad").items():
+            if float(ref.abs().max()) > 0:
+                assert rel_err(res["grads"][k], ref) < 1e-3, (step, k)
+        for k, ref in g.group(p + "s_sd_after").items():
+            assert float((s_sd[k] - ref).abs().max()) < 2e-5, k
