@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Glow CIFAR-10 teacher(K=32) -> student(K=8) distillation training_step.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,13 +10,21 @@ A "step" = teacher forward (no grad) + student forward/backward + MSE hints on l
 [0,10,20,28]/[0,34,68,100] + global-norm clip 30 + Adam, on a synthetic
 CIFAR-shaped batch of 64 images per GPU already resident in HBM.  Rank 0 prints ONE JSON line.
 
-Extra legs (rank 0, N=1 only):
-  roofline     : K more (eager) steps with every GEMM-engine / fused-step launch bracketed by HIP events on
-                 its own stream (nfk_profile_*); for the kernel class with the largest total time: algorithmic
-                 FLOP/s against the dense MFMA peak of the compute dtype (157.3 TFLOP/s f32, 2.5 PFLOP/s bf16)
-                 or algorithmic bytes/s against HBM (8 TB/s), whichever bound gives the larger minimum time.
-  cpu_baseline : the CPU oracle (oracle/glow_oracle.py, a checked restatement of the reference)
-                 running the same step on the host cores for a bounded number of steps.
+Extra objects on the line (rank 0, N=1 only):
+  roofline        : K more (eager) steps with every GEMM-engine / fused-step launch bracketed by HIP events on
+                    its own stream (nfk_profile_*); for the kernel class with the largest total time: algorithmic
+                    FLOP/s against the dense MFMA peak of the compute dtype (157.3 TFLOP/s f32, 2.5 PFLOP/s bf16)
+                    or algorithmic bytes/s against HBM (8 TB/s), whichever bound gives the larger minimum time.
+  step_roofline   : the WHOLE step: 14.04 GFLOP per image x images / measured step time against the
+                    same MFMA peak.
+  f32_parity_mode : the same step in the reference's precision (the mode that meets the 1e-5 parity bar), timed the
+                    same way, with its own dominant-kernel roofline and step roofline (skip: --no-other-precision).
+  bpd_check       : student bits/dim of ONE batch (same images, same dequantisation noise, initial parameters) in
+                    bf16 mode against fp32 mode; the run FAILS (exit 3) if they differ by 0.01 or more.
+  cpu_baseline    : the CPU oracle (oracle/glow_oracle.py, a checked restatement of the reference)
+                    running the same step on the host cores for a bounded number of steps.
+The run also fails (exit 4) if the step could not be captured into a hipGraph: `config.schedule` is derived from the
+runner's state, never from the flags.
 """
 import argparse
 import json
@@ -35,6 +43,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec)
+GFLOP_PER_IMAGE = 14.04  # teacher fwd (8.023) + 3 x student fwd (2.006) per distillation step
+PMC_PROFILE = "r02_pmc_traffic_bf16.json"   # profiles/: FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
 
 
 def cifar_cfg(K):
@@ -43,14 +53,14 @@ def cifar_cfg(K):
                 learn_top=False, y_condition=False, is_1d=False)
 
 
-def make_models(device):
+def make_models(device, dtype):
     import nf_distillation_amd as nfa
     from param_util import randomize_state_dict, shapes_of
     models = []
     for K, seed in ((8, 11), (32, 12)):
         m = nfa.create_glow_model(cifar_cfg(K))
         m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), seed))
-        models.append(m.to(device))
+        models.append(m.to(device).set_compute_dtype(dtype))
     return models  # student, teacher
 
 
@@ -81,16 +91,165 @@ def cpu_baseline(batch, steps):
                       f"torch CPU {torch.__version__}"}
 
 
+class Leg:
+    """One precision's models, step object and (captured) runner."""
+
+    def __init__(self, args, dtype, device, data, world):
+        from nf_distillation_amd.training import DistillationStep
+        self.args, self.dtype, self.data, self.world = args, dtype, data, world
+        self.student, self.teacher = make_models(device, dtype)
+        self.step = DistillationStep(self.student, self.teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
+        if not args.no_overlap:
+            self.step.enable_concurrency()  # teacher fwd || student fwd, wgrad || dgrad on side streams
+        self.runner, self.pipelined = self.step, False
+
+    def initial_bpd(self, x, noise):
+        """Student bits/dim of one batch with the initial parameters (no training)."""
+        with torch.no_grad():
+            _, bpd, _ = self.student(x.clone(), None, noise=noise)
+        return float(bpd.mean())
+
+    def capture(self):
+        a, data = self.args, self.data
+        if not a.no_overlap:
+            self.step.enable_concurrency()   # (the auxiliary stream is a library-wide setting: the other leg may have reset it)
+        self.pipelined = not a.no_graph and not a.no_pipeline
+        if self.pipelined:
+            # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
+            # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py)
+            from nf_distillation_amd.pipeline import PipelinedStep
+            self.runner = PipelinedStep(self.step, data[0], strict=True)
+            self.runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
+        elif not a.no_graph:
+            from nf_distillation_amd.training import CapturedStep
+            self.runner = CapturedStep(self.step, data[0], strict=True)
+            self.runner.prepare()  # eager warm-up + capture, before the W warm-up steps
+        if not a.no_graph and getattr(self.runner, "graph", None) is None:
+            print("bench.py: the step was not captured into a hipGraph", file=sys.stderr)
+            raise SystemExit(4)
+
+    def schedule(self):
+        """What is actually running, read from the runner (never from the flags)."""
+        graph = getattr(self.runner, "graph", None) is not None
+        if graph and self.pipelined:
+            s = "hipGraph replay, teacher(t+1) || student(t) software pipeline"
+        elif graph:
+            s = "hipGraph replay"
+        else:
+            s = "eager"
+        if self.world > 1 and graph:
+            s += ", gradient all-reduce between sub-graphs (never captured)"
+        return s
+
+    def run(self, n, eager=False):
+        data, nb, last = self.data, len(self.data), None
+        for i in range(n):
+            if eager:
+                last = self.step.training_step(data[i % nb].clone())
+            elif self.pipelined:
+                last = self.runner.training_step(data[(i + 1) % nb])   # trains on the batch supplied by the previous call
+            else:
+                last = self.runner.training_step(data[i % nb].clone())
+        return last
+
+    def timed(self, steps, warmup, device):
+        from nf_distillation_amd.dist import max_over_ranks
+        self.run(warmup)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = self.run(steps)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return max_over_ranks(time.perf_counter() - t0, device), last
+
+    def sequential_schedule(self, steps, warmup):
+        """The same step without the cross-step software pipeline (teacher and student of the same batch inside one
+        call, one hipGraph) -- reported beside the headline value, never instead of it."""
+        from nf_distillation_amd.training import CapturedStep
+        data, nb = self.data, len(self.data)
+        seq = CapturedStep(self.step, data[0], strict=True)
+        seq.prepare()
+        for i in range(warmup):
+            seq.training_step(data[i % nb].clone())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            seq.training_step(data[i % nb].clone())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": self.args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps,
+                "schedule": "hipGraph replay, teacher and student of the same batch per call"}
+
+    def roofline(self, steps):
+        """HIP events bracket each launch: eager steps (outside the captured graph), on ONE stream, so that a launch's
+        duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r02_*)."""
+        from nf_distillation_amd import capi
+        self.step.enable_concurrency(False)
+        if self.pipelined:   # both models run their deep-level fused steps with the pipelined schedule's split policy
+            self.teacher.flow.engine().fused_split_inference = self.runner.teacher_split
+            self.student.flow.engine().fused_split_training = self.runner.student_split
+        self.run(2, eager=True)
+        capi.profile_begin()
+        self.run(steps, eager=True)
+        prof = capi.profile_end()
+        dom = max(prof, key=lambda d: d["ms"])
+        n = max(dom["launches"], 1)
+        avg_s = dom["ms"] * 1e-3 / n
+        flops, nbytes = dom["flops"] / n, dom["bytes"] / n          # algorithmic, per launch (DESIGN.md §4)
+        mfma_peak = F32_MFMA_PEAK_TFLOPS if self.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+        # the roofline that bounds this kernel is the one with the larger minimum time
+        hbm_bound = nbytes / (HBM_PEAK_GBPS * 1e9) > flops / (mfma_peak * 1e12)
+        if hbm_bound:
+            achieved, peak, unit = nbytes / avg_s / 1e9, HBM_PEAK_GBPS, "GB/s"
+        else:
+            achieved, peak, unit = flops / avg_s / 1e12, mfma_peak, "TFLOP/s"
+        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE with the gfx950
+        # fetch correction, tools/pmc_traffic.py) -- bench.py cannot collect counters itself; null if the profile does
+        # not hold this kernel
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", PMC_PROFILE)
+        if self.dtype == "bf16" and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            name = pmc.get("bench_class_symbols", {}).get(dom["kernel"])
+            kern = pmc.get("kernels", {})
+            if name in kern:
+                traffic, traffic_src = kern[name]["hbm_bytes_per_launch_corrected"], "profiles/" + PMC_PROFILE
+        return {
+            "bound": "hbm" if hbm_bound else "mfma",
+            "kernel": dom["kernel"] + (" [bf16 operands]" if self.dtype == "bf16" else " [f32]"),
+            "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
+            "traffic_source": traffic_src,
+            "launches_per_step": dom["launches"] / steps, "avg_launch_us": 1e6 * avg_s,
+            "algorithmic_gflop_per_launch": flops / 1e9, "algorithmic_mbytes_per_launch": nbytes / 1e6,
+            "achieved_tflops": flops / avg_s / 1e12,
+            "gemm_ms_per_step": {d["kernel"]: d["ms"] / steps for d in prof if d["launches"]},
+        }
+
+
+def step_roofline(images_per_s, dtype):
+    peak = F32_MFMA_PEAK_TFLOPS if dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    tf = images_per_s * GFLOP_PER_IMAGE / 1e3
+    return {"algorithmic_gflop_per_image": GFLOP_PER_IMAGE, "achieved_tflops": tf, "peak_tflops": peak, "frac": tf / peak,
+            "note": "whole distillation step (all kernels, launch gaps, optimiser) against the dense MFMA peak"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling instead: fixed global batch (SURVEY.md §8d suggests 512), split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-precision", action="store_true",
+                    help="skip the second leg (the f32 parity mode beside a bf16 headline, or the reverse)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-overlap", action="store_true", help="keep every kernel on one stream")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -104,7 +263,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "
-                         "coupling-net convs (BASELINE.json config 2; bits/dim within 0.01: tests/test_gpu_bf16.py)")
+                         "coupling-net convs (BASELINE.json config 2; bits/dim within 0.01: tests/test_gpu_fullsize.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,8 +283,6 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
-    from nf_distillation_amd.dist import max_over_ranks
-    from nf_distillation_amd.training import DistillationStep
     from nf_distillation_amd import capi
     from param_util import synthetic_images
 
@@ -133,137 +290,64 @@ def main():
         capi.lib().nfk_set_tuning(args.tuning)
     if args.bwd_mode is not None:
         capi.lib().nfk_set_bwd_mode(args.bwd_mode)
-    student, teacher = make_models(device)
-    student.set_compute_dtype(args.dtype)
-    teacher.set_compute_dtype(args.dtype)
-    step = DistillationStep(student, teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
-    if not args.no_overlap:
-        step.enable_concurrency()  # teacher fwd || student fwd, wgrad || dgrad on side streams
 
     # synthetic data, resident in HBM before the timed region; a few distinct batches, cycled
     nb = 4
     data = [synthetic_images(args.batch, seed=1000 + 17 * rank + i)[0].to(device) for i in range(nb)]
+    solo = rank == 0 and world == 1
 
-    # one hipGraph for the whole step (fwd + bwd + clip + Adam); the host only copies the batch in and replays
-    runner = step
-    pipelined = not args.no_graph and not args.no_pipeline
-    if pipelined:
-        # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
-        # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py)
-        from nf_distillation_amd.pipeline import PipelinedStep
-        runner = PipelinedStep(step, data[0])
-        runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
-    elif not args.no_graph:
-        from nf_distillation_amd.training import CapturedStep
-        runner = CapturedStep(step, data[0])
-        runner.prepare()  # eager warm-up + capture, before the W warm-up steps
+    leg = Leg(args, args.dtype, device, data, world)
+    other = None
+    bpd_check = None
+    if solo and not args.no_other_precision:
+        other = Leg(args, "f32" if args.dtype == "bf16" else "bf16", device, data, world)
+        xb, noise = synthetic_images(args.batch, seed=77)
+        xb, noise = xb.to(device), noise.to(device)
+        bpd = {leg.dtype: leg.initial_bpd(xb, noise), other.dtype: other.initial_bpd(xb, noise)}
+        diff = abs(bpd["bf16"] - bpd["f32"])
+        bpd_check = {"student_bpd_bf16": bpd["bf16"], "student_bpd_f32": bpd["f32"], "abs_diff": diff, "bar": 0.01,
+                     "ok": diff < 0.01, "sample": f"one batch of {args.batch} images, same dequantisation noise, initial parameters"}
 
-    def run(n, eager=False):
-        last = None
-        for i in range(n):
-            if eager:
-                last = step.training_step(data[i % nb].clone())
-            elif pipelined:
-                last = runner.training_step(data[(i + 1) % nb])   # trains on the batch supplied by the previous call
-            else:
-                last = runner.training_step(data[i % nb].clone())
-        return last
-
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0, device)
-
+    leg.capture()
+    elapsed, last = leg.timed(args.steps, args.warmup, device)
     images = args.batch * world * args.steps
+    value = images / elapsed
     result = {
         "metric": "train images/sec Glow CIFAR-10 distillation step",
-        "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "Glow CIFAR-10 32x32 distillation training_step: teacher L=3 K=32 h=512 fwd (no grad) + "
                                "student L=3 K=8 h=512 fwd+bwd + MSE hints + clip 30 + Adam",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "schedule": ("hipGraph replay, teacher(t+1) || student(t) software pipeline" if pipelined else
-                                ("eager" if args.no_graph else "hipGraph replay"))},
+                   "schedule": leg.schedule()},
         "student_bpd": float(last["nll"]), "loss": float(last["result_loss"]),
+        "step_roofline": step_roofline(value / world, args.dtype),
     }
-
-    if rank == 0 and world == 1 and pipelined and not args.no_roofline:
-        # for reference: the same step without the cross-step software pipeline (teacher and student of the same batch
-        # inside one call, one hipGraph) -- reported beside the headline value, never instead of it
-        from nf_distillation_amd.training import CapturedStep
-        seq = CapturedStep(step, data[0])
-        seq.prepare()
-        for i in range(args.warmup):
-            seq.training_step(data[i % nb].clone())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            seq.training_step(data[i % nb].clone())
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        result["sequential_schedule"] = {"value": args.batch * args.steps / dt, "unit": "images/s",
-                                         "ms_per_step": 1e3 * dt / args.steps,
-                                         "schedule": "hipGraph replay, teacher and student of the same batch per call"}
-
-    if rank == 0 and world == 1 and not args.no_roofline:
-        # HIP events bracket each launch: eager steps (outside the captured graph), on ONE stream, so that a launch's
-        # duration is the kernel's own -- the same thing rocprofv3 --kernel-trace reports (profiles/r01_h_*)
-        step.enable_concurrency(False)
-        if pipelined:   # both models run their deep-level fused steps with the pipelined schedule's split policy
-            teacher.flow.engine().fused_split_inference = runner.teacher_split
-            student.flow.engine().fused_split_training = runner.student_split
-        run(2, eager=True)
-        capi.profile_begin()
-        run(args.steps, eager=True)
-        prof = capi.profile_end()
-        dom = max(prof, key=lambda d: d["ms"])
-        n = max(dom["launches"], 1)
-        avg_s = dom["ms"] * 1e-3 / n
-        flops, nbytes = dom["flops"] / n, dom["bytes"] / n          # algorithmic, per launch
-        mfma_peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-        # the roofline that bounds this kernel is the one with the larger minimum time
-        hbm_bound = nbytes / (HBM_PEAK_GBPS * 1e9) > flops / (mfma_peak * 1e12)
-        if hbm_bound:
-            achieved, peak, unit = nbytes / avg_s / 1e9, HBM_PEAK_GBPS, "GB/s"
-        else:
-            achieved, peak, unit = flops / avg_s / 1e12, mfma_peak, "TFLOP/s"
-        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE with the gfx950
-        # fetch correction, tools/pmc_traffic.py) -- bench.py cannot collect counters itself; null if the profile does
-        # not hold this kernel
-        traffic, traffic_src = None, None
-        sym = {"<*,1,*>": "nfk::fused2_step_fwd_kernel<3, 1, 4, 1>", "<*,2,*>": "nfk::fused2_step_fwd_kernel<2, 2, 8, 4>",
-               "<*,3,*>": "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>"}   # levels 2 / 3: the student's instances
-        pmc_file = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_bf16.json")
-        if args.dtype == "bf16" and os.path.exists(pmc_file):
-            kern = json.load(open(pmc_file)).get("kernels", {})
-            for tag, name in sym.items():
-                if tag in dom["kernel"] and name in kern:
-                    traffic, traffic_src = kern[name]["hbm_bytes_per_launch_corrected"], "profiles/r01_h_pmc_traffic_bf16.json"
-        result["roofline"] = {
-            "bound": "hbm" if hbm_bound else "mfma",
-            "kernel": dom["kernel"] + (" [bf16 operands]" if args.dtype == "bf16" else " [f32]"),
-            "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-            "launches_per_step": dom["launches"] / args.steps, "avg_launch_us": 1e6 * avg_s,
-            "algorithmic_gflop_per_launch": flops / 1e9, "algorithmic_mbytes_per_launch": nbytes / 1e6,
-            "achieved_tflops": flops / avg_s / 1e12,
-            "gemm_ms_per_step": {d["kernel"]: d["ms"] / args.steps for d in prof},
-        }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and leg.pipelined and not args.no_roofline:
+        result["sequential_schedule"] = leg.sequential_schedule(args.steps, args.warmup)
+    if solo and not args.no_roofline:
+        result["roofline"] = leg.roofline(args.steps)
+    if other is not None:
+        other.capture()
+        dt, last_o = other.timed(args.steps, args.warmup, device)
+        v = args.batch * args.steps / dt
+        block = {"value": v, "unit": "images/s", "ms_per_step": 1e3 * dt / args.steps, "dtype": other.dtype,
+                 "schedule": other.schedule(), "student_bpd": float(last_o["nll"]), "step_roofline": step_roofline(v, other.dtype)}
+        if not args.no_roofline:
+            block["roofline"] = other.roofline(args.steps)
+        result["f32_parity_mode" if other.dtype == "f32" else "bf16_throughput_mode"] = block
+        result["bpd_check"] = bpd_check
+    if solo and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_steps)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if bpd_check is not None and not bpd_check["ok"]:
+        print("bench.py: bf16 student bits/dim differs from fp32 by >= 0.01", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

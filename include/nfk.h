@@ -292,9 +292,12 @@ int nfk_postprocess_u8(const float *x_nchw, unsigned char *u8_hwc, int B, int H,
  * s_p / t_p: P pairs of dense per-sample-contiguous tensors with per_sample[p] elements per sample (same memory order
  * in both).  fwd: part [P][B] scratch, kd_out [B], out3 = {result, mean nll, mean kd}; fixed-order sums.
  * bwd: g_result is a device scalar; writes g_s[p] (shape of s_p) and g_nll [B] (may be NULL). */
-#define NFK_KD_MAX_PAIRS 8
+#define NFK_KD_MAX_PAIRS 16
 typedef struct nfk_kd_pairs {
-  int32_t n, B;
+  int32_t n, B;         /* n = number of (student, teacher) hint pairs = min(len(s_idx), len(t_idx)): the reference ZIPS
+                           the two index lists (pl_module.py:264-267) */
+  int32_t divisor, pad_; /* len(student_kd_indices) (pl_module.py:279-281), >= n; 0 means n */
+  const float *weights; /* optional per-sample weights multiplied into the loss (pl_module.py:309-310), or NULL */
   const float *s[NFK_KD_MAX_PAIRS], *t[NFK_KD_MAX_PAIRS];
   int64_t per_sample[NFK_KD_MAX_PAIRS];
 } nfk_kd_pairs;

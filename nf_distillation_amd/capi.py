@@ -75,12 +75,16 @@ class TabGrads(C.Structure):
     _fields_ = [("gW", c_fp * 6), ("gb", c_fp * 6)]
 
 
+KD_MAX_PAIRS = 16   # NFK_KD_MAX_PAIRS
+
+
 class KdPairs(C.Structure):
-    _fields_ = [("n", C.c_int32), ("B", C.c_int32), ("s", c_fp * 8), ("t", c_fp * 8), ("per_sample", C.c_int64 * 8)]
+    _fields_ = [("n", C.c_int32), ("B", C.c_int32), ("divisor", C.c_int32), ("pad_", C.c_int32), ("weights", c_fp),
+                ("s", c_fp * KD_MAX_PAIRS), ("t", c_fp * KD_MAX_PAIRS), ("per_sample", C.c_int64 * KD_MAX_PAIRS)]
 
 
 class KdGrads(C.Structure):
-    _fields_ = [("g_s", c_fp * 8), ("g_nll", c_fp)]
+    _fields_ = [("g_s", c_fp * KD_MAX_PAIRS), ("g_nll", c_fp)]
 
 
 class RepackDesc(C.Structure):

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 using namespace nfk;
 // ------------------------------------------------------------------------------------------
 // Distillation loss (NFModel.loss, pl_module.py:246-300 for the hint-MSE + NLL branch):
-//   kd[b] = 1/P * sum_p mean_i (s_p[b][i] - t_p[b][i])^2 ,  result = mean_b (w_nll * nll[b] + w_kd * kd[b])
+//   kd[b] = 1/D * sum_{p<P} mean_i (s_p[b][i] - t_p[b][i])^2 ,  result = mean_b (w_nll * nll[b] + w_kd * kd[b]) [* weights[b]]
+//   (P zipped pairs, D = len(student_kd_indices) >= P)
 // two launches forward (per (sample, pair) sums, then one workgroup combines in fixed order), one backward.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) kd_pair_sums_kernel(nfk_kd_pairs a, float* __restrict__ part) {
@@ -92,9 +93,10 @@ __global__ void __launch_bounds__(256) kd_combine_kernel(nfk_kd_pairs a, const f
   for (int b = threadIdx.x; b < a.B; b += 256) {
     float kd = 0.f;
     for (int p = 0; p < a.n; ++p) kd += part[p * a.B + b];
-    kd /= (float)(a.n > 0 ? a.n : 1);
+    kd /= (float)(a.divisor > 0 ? a.divisor : (a.n > 0 ? a.n : 1));
     kd_out[b] = kd;
-    r += w_nll * nll[b] + w_kd * kd;
+    const float per = w_nll * nll[b] + w_kd * kd;
+    r += a.weights ? per * a.weights[b] : per;
     sn += nll[b];
     sk += kd;
   }
@@ -107,10 +109,10 @@ __global__ void __launch_bounds__(256) kd_combine_kernel(nfk_kd_pairs a, const f
 __global__ void __launch_bounds__(256) kd_bwd_kernel(nfk_kd_pairs a, const float* __restrict__ g_result, float w_nll,
                                                      float w_kd, nfk_kd_grads g) {
   const int b = blockIdx.x, p = blockIdx.y;
-  const float gr = g_result[0];
+  const float gr = a.weights ? g_result[0] * a.weights[b] : g_result[0];
   if (p == 0 && threadIdx.x == 0 && g.g_nll) g.g_nll[b] = gr * w_nll / (float)a.B;
   const long n = a.per_sample[p];
-  const float coef = gr * w_kd * 2.f / ((float)a.B * (float)a.n * (float)n);
+  const float coef = gr * w_kd * 2.f / ((float)a.B * (float)(a.divisor > 0 ? a.divisor : a.n) * (float)n);
   const float* s = a.s[p] + (long)b * n;
   const float* t = a.t[p] + (long)b * n;
   float* o = g.g_s[p] + (long)b * n;
@@ -199,7 +201,8 @@ int nfk_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, co
 }
 int nfk_kd_loss_fwd(const nfk_kd_pairs* pairs, const float* nll, float w_nll, float w_kd, float* part, float* kd_out,
                     float* out3, void* stream) {
-  if (pairs->B <= 0 || pairs->n < 0 || pairs->n > NFK_KD_MAX_PAIRS) return NFK_ERR_ARG;
+  if (pairs->B <= 0 || pairs->n < 0 || pairs->n > NFK_KD_MAX_PAIRS || (pairs->divisor && pairs->divisor < pairs->n))
+    return NFK_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (pairs->n > 0) {
     hipLaunchKernelGGL(kd_pair_sums_kernel, dim3(pairs->B, pairs->n), dim3(256), 0, st, *pairs, part);

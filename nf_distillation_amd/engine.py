@@ -71,14 +71,17 @@ class FlowEngine:
         return self._params
 
     def _tensors(self):
-        """Parameters and buffers of all layers (Parameter objects are stable; their .data may be re-homed)."""
+        """Parameters and buffers of all layers.  Parameter objects are stable (their .data may be re-homed) and are
+        listed once; buffers are REPLACED by `Module.to()` and by `inherit_permutation_matrix` (`invconv.p = ...`), so
+        they are read from the modules' buffer dicts on every call."""
         if self._tensor_list is None:
-            ts = []
+            ts, holders = [], []
             for l in self.layers:
                 ts.extend(l.parameters())
-                ts.extend(l.buffers())
-            self._tensor_list = ts
-        return self._tensor_list
+                holders.extend(m for m in l.modules() if m._buffers)
+            self._tensor_list, self._buffer_holders = ts, holders
+        bufs = [b for m in self._buffer_holders for b in m._buffers.values() if b is not None]
+        return self._tensor_list + bufs
 
     def _signature(self):
         return tuple([t.data_ptr() for t in self._tensors()])
@@ -403,6 +406,18 @@ class _Scratch:
         return out
 
 
+def _cached_grad_desc(st, tag, pg, dev):
+    """Device copy of the nfk_prep_grad descriptors, uploaded only when a pointer in them changed (the workspaces and the
+    flat gradient arena are persistent, so after the first step this is a lookup: no host-to-device copy on the hot path,
+    none inside a hipGraph capture)."""
+    sig = tuple((d.part, d.nparts, d.g_an_bias, d.g_an_logs, d.g_lower, d.g_upper, d.g_log_s, d.g_weight) for d in pg)
+    key = "grad_desc_" + tag
+    cached = st.get(key)
+    if cached is None or cached[0] != sig:
+        cached = st[key] = (sig, capi.struct_array_to_device(pg, dev))
+    return cached[1]
+
+
 class _DecodeFn(torch.autograd.Function):
     """The reverse pass of a 1-D FlowNet (models/kd_flows.py:55-73) with gradients, as one autograd node: parameter
     gradients are accumulated straight into `.grad` (as _EncodeFn does); returns every intermediate tensor."""
@@ -419,13 +434,13 @@ class _DecodeFn(torch.autograd.Function):
             cur, sv = r.tab.inverse(cur, y_onehot, need=True)
             outs.append(cur)
             saved.append(sv)
-        ctx.eng, ctx.saved, ctx.y_onehot = eng, saved, y_onehot
+        ctx.eng, ctx.saved, ctx.y_onehot, ctx.st = eng, saved, y_onehot, st
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *g_outs):
         eng = ctx.eng
-        st = eng.state
+        st = ctx.st   # the state the forward ran with (another call may have rebuilt eng.state for another batch size)
         lib, s = capi.lib(), capi.stream()
         recs = st["recs"]
         dev = ctx.saved[0][0].device
@@ -462,9 +477,8 @@ class _DecodeFn(torch.autograd.Function):
                     d.g_weight = ptr(ic.weight.grad)
             pg.append(d)
         if any(d.nparts > 0 for d in pg):
-            grad_dev = capi.struct_array_to_device(pg, dev)
+            grad_dev = _cached_grad_desc(st, "inv", pg, dev)
             check(lib.nfk_prep_inv_bwd(ptr(st["prep_dev"]), ptr(grad_dev), st["n_prep"], None, B, s), "nfk_prep_inv_bwd")
-            ctx.keep = (grad_dev,)
         gz = g if ctx.needs_input_grad[1] else None
         return (None, gz, g_y if want_gy else None) + (None,) * len(eng.params())
 
@@ -480,7 +494,7 @@ class _EncodeFn(torch.autograd.Function):
         B, dev = x.shape[0], x.device
         need = any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)
-        ctx.eng, ctx.need, ctx.B = eng, need, B
+        ctx.eng, ctx.need, ctx.B, ctx.st = eng, need, B, st
         ld = logdet.to(torch.float32).contiguous()
         outs, saved = [], []
         if eng.is_1d:
@@ -605,7 +619,7 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         eng, B = ctx.eng, ctx.B
-        st = eng.state
+        st = ctx.st   # the state the forward ran with (another call may have rebuilt eng.state for another batch size)
         lib, s = capi.lib(), capi.stream()
         recs = st["recs"]
         g_outs, g_ld = grads[:-1], grads[-1]
@@ -642,10 +656,9 @@ class _EncodeFn(torch.autograd.Function):
                         d.g_weight = ptr(ic.weight.grad)
                 pg.append(d)
             if all(d.nparts > 0 for d in pg):
-                grad_dev = capi.struct_array_to_device(pg, dev)
+                grad_dev = _cached_grad_desc(st, "fwd", pg, dev)
                 check(lib.nfk_prep_bwd(ptr(st["prep_dev"]), ptr(grad_dev), st["n_prep"], ptr(g_ld), B, st["any_dense"], s),
                       "nfk_prep_bwd")
-                ctx.keep = (grad_dev,)
             elif any(d.nparts > 0 for d in pg):
                 raise RuntimeError("partial backward through a 1-D flow is not supported")
             gx = g if ctx.needs_input_grad[1] else None

@@ -50,8 +50,10 @@ class _ActNorm(nn.Module):
         with torch.no_grad():
             bias = -torch.mean(input, dim=dims, keepdim=True)
             var = torch.mean((input + bias) ** 2, dim=dims, keepdim=True)
-            self.bias.data.copy_(bias)
-            self.logs.data.copy_(torch.log(self.scale / (torch.sqrt(var) + 1e-6)))
+            # in-place on the Parameters themselves (not on .data): bumps their version counters, which is what tells a
+            # FlowEngine that cached W.diag(e^logs) products of a frozen model are stale
+            self.bias.copy_(bias)
+            self.logs.copy_(torch.log(self.scale / (torch.sqrt(var) + 1e-6)))
             self.inited = True
 
     def forward(self, input, logdet=None, reverse=False):
@@ -481,8 +483,12 @@ def inherit_permutation_matrix(student, teacher, student_kd_indices, teacher_kd_
     acc = None
     for t_id, t_layer in enumerate(teacher.flow.layers):
         if t_id == teacher_kd_indices[k]:
+            # `None @ p` upstream when no FlowStep lies between two hint layers: the same TypeError here
             student.flow.layers[student_kd_indices[k]].invconv.p = acc @ t_layer.invconv.p
             k += 1
             acc = None
         elif isinstance(t_layer, FlowStep):
             acc = t_layer.invconv.p if acc is None else acc @ t_layer.invconv.p
+    eng = getattr(student.flow, "_engine", None)
+    if eng is not None:
+        eng.mark_dirty()   # cached W = P.L.U products are stale

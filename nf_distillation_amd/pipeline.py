@@ -29,9 +29,13 @@ from .training import DistillationStep, distillation_loss
 
 
 class PipelinedStep:
-    def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2, with_noise=False):
+    def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2, with_noise=False, strict=False):
+        self.strict = strict    # True: a failed capture raises instead of degrading to eager execution
         if step.teacher is None or step.w_kd <= 0:
             raise ValueError("pipelining needs a teacher with kd_weight > 0")
+        if getattr(step.student, "y_condition", False) or step.w_perc > 0:
+            # conditional / tabular recipes are launch-bound 1-D flows; they run through DistillationStep / CapturedStep
+            raise ValueError("the software pipeline covers the unconditional image recipe (no y_onehot, no perceptual branch)")
         self.step = step
         self.x_in = torch.empty_like(example_x)        # incoming batch t+1
         self.x_stu_next = torch.empty_like(example_x)  # batch t+1 + student noise (student input of the next call)
@@ -174,6 +178,8 @@ class PipelinedStep:
             try:
                 self._capture()
             except Exception as exc:  # pragma: no cover - depends on the runtime
+                if self.strict:
+                    raise
                 import warnings
                 warnings.warn(f"hipGraph capture of the pipelined step failed ({exc!r}); running eagerly")
                 self.use_graph = False

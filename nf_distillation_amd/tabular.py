@@ -31,8 +31,16 @@ class TabStep:
         lib = capi.lib()
         self.nblk = lib.nfk_tab_bwd_blocks(C.byref(s))
         self.nparam = lib.nfk_tab_param_floats(C.byref(s))
-        self.part_mix = None
+        self.part_mix = None       # partial (gW, gc) rows of the last backward; None = this step's backward has not run
         self.part_mix_inv = None
+        self._bufs = {}            # persistent workspaces (stable pointers: descriptors are uploaded once, and a captured
+                                   # hipGraph replays against the same addresses)
+
+    def _buf(self, name, numel, device):
+        t = self._bufs.get(name)
+        if t is None or t.numel() != numel or t.device != device:
+            t = self._bufs[name] = torch.empty(numel, device=device, dtype=torch.float32)
+        return t
 
     def _cond(self, y_onehot, forward):
         # forward conditions on "y given", reverse on "model has condition features" (models/flows.py:152 vs :177)
@@ -69,8 +77,8 @@ class TabStep:
         for k, li in enumerate(_LIN):
             g.gW[k], g.gb[k] = ptr(blk[li].weight.grad), ptr(blk[li].bias.grad)
         d = self.cs.d
-        part = torch.empty(self.nblk * self.nparam, device=y.device, dtype=torch.float32)
-        self.part_mix_inv = torch.empty(self.nblk * (d * d + d), device=y.device, dtype=torch.float32)
+        part = self._buf("part_inv", self.nblk * self.nparam, y.device)
+        self.part_mix_inv = self._buf("mix_inv", self.nblk * (d * d + d), y.device)
         gy = torch.empty_like(y)
         gcond = torch.zeros_like(cond) if (cond is not None and want_gcond) else None
         check(lib.nfk_tab_inv_bwd(C.byref(self.cs), C.byref(g), ptr(y), ptr(cond), ptr(g_x), None, ptr(gy), ptr(gcond),
@@ -86,8 +94,8 @@ class TabStep:
         for k, li in enumerate(_LIN):
             g.gW[k], g.gb[k] = ptr(blk[li].weight.grad), ptr(blk[li].bias.grad)
         d = self.cs.d
-        part = torch.empty(self.nblk * self.nparam, device=x.device, dtype=torch.float32)
-        self.part_mix = torch.empty(self.nblk * (d * d + d), device=x.device, dtype=torch.float32)
+        part = self._buf("part", self.nblk * self.nparam, x.device)
+        self.part_mix = self._buf("mix", self.nblk * (d * d + d), x.device)
         gx = torch.empty_like(x)
         gcond = torch.zeros_like(cond) if (cond is not None and want_gcond) else None
         check(lib.nfk_tab_bwd(C.byref(self.cs), C.byref(g), ptr(x), ptr(cond), ptr(g_out), ptr(g_ld), ptr(gx), ptr(gcond),

@@ -21,8 +21,12 @@ from .dist import GradAllReducer
 from .modules import FlowStep, SqueezeLayer
 
 
-def kd_indices(student, teacher, student_is_1d=False):
-    """NFModel._get_kd_indices (pl_module.py:81-110)."""
+def kd_indices(student, teacher, student_is_1d=None):
+    """NFModel._get_kd_indices (pl_module.py:81-110).  `student_is_1d` is params["student"]["is_1d"] upstream; by
+    default it is read from the student model."""
+    if student_is_1d is None:
+        student_is_1d = bool(getattr(student, "is_1d", False))
+
     def pick(model, mult):
         layers = model.flow.layers
         return [i for i, l in enumerate(layers)
@@ -139,12 +143,17 @@ class _KdLossFn(torch.autograd.Function):
     the ~45 elementwise / reduction kernels the same expression costs as tensor ops."""
 
     @staticmethod
-    def forward(ctx, s_nll, w_nll, w_kd, n_pairs, *tensors):
+    def forward(ctx, s_nll, w_nll, w_kd, n_pairs, divisor, weights, *tensors):
         s_list, t_list = tensors[:n_pairs], tensors[n_pairs:]
         capi.require_cuda(s_nll, "s_nll")
         B = s_nll.shape[0]
+        if n_pairs > capi.KD_MAX_PAIRS:
+            raise ValueError(f"at most {capi.KD_MAX_PAIRS} hint pairs are supported, got {n_pairs}")
         pairs = capi.KdPairs()
-        pairs.n, pairs.B = n_pairs, B
+        pairs.n, pairs.B, pairs.divisor = n_pairs, B, max(int(divisor), n_pairs)
+        if weights is not None:
+            weights = weights.detach().to(torch.float32).reshape(B).contiguous()
+            pairs.weights = weights.data_ptr()
         for i, (s, t) in enumerate(zip(s_list, t_list)):
             pairs.per_sample[i] = _dense_pair(s, t)
             pairs.s[i], pairs.t[i] = s.data_ptr(), t.data_ptr()
@@ -155,14 +164,14 @@ class _KdLossFn(torch.autograd.Function):
         capi.check(capi.lib().nfk_kd_loss_fwd(C.byref(pairs), capi.ptr(nll), float(w_nll), float(w_kd), capi.ptr(part),
                                               capi.ptr(kd), capi.ptr(out3), capi.stream()), "nfk_kd_loss_fwd")
         ctx.pairs, ctx.w = pairs, (float(w_nll), float(w_kd))
-        ctx.keep = (s_list, t_list, nll)
+        ctx.keep = (s_list, t_list, nll, weights)
         ctx.n_pairs = n_pairs
         ctx.mark_non_differentiable(kd)
         return out3[0], out3[1].detach(), out3[2].detach(), kd
 
     @staticmethod
     def backward(ctx, g_result, _g1, _g2, _g3):
-        s_list, _, nll = ctx.keep
+        s_list, _, nll, weights = ctx.keep
         g = g_result.detach().to(torch.float32).reshape(1).contiguous()
         grads = capi.KdGrads()
         g_s = [torch.empty_like(s) for s in s_list]   # preserves the (channels-last) strides
@@ -174,13 +183,18 @@ class _KdLossFn(torch.autograd.Function):
             capi.check(capi.lib().nfk_kd_loss_bwd(C.byref(ctx.pairs), capi.ptr(g), ctx.w[0], ctx.w[1], C.byref(grads),
                                                   capi.stream()), "nfk_kd_loss_bwd")
         else:
-            g_nll = g * (ctx.w[0] / nll.shape[0]) * torch.ones_like(nll)
-        return (g_nll, None, None, None) + tuple(g_s) + (None,) * len(g_s)
+            g_nll = g * (ctx.w[0] / nll.shape[0]) * (weights if weights is not None else torch.ones_like(nll))
+        return (g_nll, None, None, None, None, None) + tuple(g_s) + (None,) * len(g_s)
 
 
-def distillation_loss(s_nll, s_hints, t_hints, w_nll, w_kd):
-    """-> dict(nll, kd, result_loss) as NFModel.loss logs them; only result_loss carries a gradient."""
-    result, nll_m, kd_m, _ = _KdLossFn.apply(s_nll, w_nll, w_kd, len(s_hints), *s_hints, *[t.detach() for t in t_hints])
+def distillation_loss(s_nll, s_hints, t_hints, w_nll, w_kd, weights=None):
+    """-> dict(nll, kd, result_loss) as NFModel.loss logs them; only result_loss carries a gradient.
+    The two hint lists are ZIPPED as upstream (pl_module.py:264-267: the shorter list decides the number of pairs)
+    while the divisor stays len(student hints) (:279-281); student hints without a partner get no gradient.
+    `weights`: optional per-sample weights multiplied into the loss before the batch mean (:309-310)."""
+    n = min(len(s_hints), len(t_hints))
+    result, nll_m, kd_m, _ = _KdLossFn.apply(s_nll, w_nll, w_kd, n, len(s_hints), weights, *s_hints[:n],
+                                             *[t.detach() for t in t_hints[:n]])
     return {"nll": nll_m, "kd": kd_m, "result_loss": result}
 
 
@@ -188,7 +202,7 @@ class DistillationStep:
     """One optimisation step of teacher->student distillation (see module docstring)."""
 
     def __init__(self, student, teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, weight_decay=0.0,
-                 clip_norm=30.0, process_group=None, bucket_bytes=16 << 20, student_is_1d=False,
+                 clip_norm=30.0, process_group=None, bucket_bytes=16 << 20, student_is_1d=None,
                  perceptual_weight=0.0):
         self.student, self.teacher = student, teacher
         self.w_nll, self.w_kd, self.w_perc = nll_weight, kd_weight, perceptual_weight
@@ -221,9 +235,17 @@ class DistillationStep:
         self._concurrent = bool(on)
         capi.lib().nfk_set_aux_stream(self._aux.cuda_stream if on else None)
 
-    def _teacher_forward(self, x, noise_teacher):
+    def _cond(self, y_onehot):
+        """pl_module.py:216-243: y goes to the models iff params["student"]["y_condition"]."""
+        if getattr(self.student, "y_condition", False):
+            if y_onehot is None:
+                raise ValueError("the student is conditional (y_condition): training_step needs y_onehot")
+            return y_onehot
+        return None
+
+    def _teacher_forward(self, x, noise_teacher, y_onehot=None):
         with torch.no_grad():
-            t_z, _, _ = self.teacher(x, None, noise=noise_teacher)
+            t_z, _, _ = self.teacher(x, y_onehot, noise=noise_teacher)
         return t_z
 
     def perceptual_l1(self, x, latent=None, y_onehot=None):
@@ -239,15 +261,17 @@ class DistillationStep:
         per = (s_x - t_x).abs().flatten(1).mean(1)
         return torch.where(torch.isnan(per), torch.zeros_like(per), per)
 
-    def forward_losses(self, x, noise_student=None, noise_teacher=None, latent=None):
-        out = self._nll_kd_losses(x, noise_student, noise_teacher)
+    def forward_losses(self, x, noise_student=None, noise_teacher=None, latent=None, y_onehot=None, weights=None):
+        y = self._cond(y_onehot)
+        out = self._nll_kd_losses(x, noise_student, noise_teacher, y, weights)
         if self.w_perc > 0:
-            per = self.perceptual_l1(x, latent).mean()
-            out["perceptual"] = per
-            out["result_loss"] = out["result_loss"] + self.w_perc * per   # mean_b of a sum = sum of the means
+            per = self.perceptual_l1(x, latent, y)
+            out["perceptual"] = per.mean()
+            # mean_b of a sum = sum of the means; the per-sample weights multiply every term (pl_module.py:301-310)
+            out["result_loss"] = out["result_loss"] + self.w_perc * (per if weights is None else per * weights).mean()
         return out
 
-    def _nll_kd_losses(self, x, noise_student=None, noise_teacher=None):
+    def _nll_kd_losses(self, x, noise_student=None, noise_teacher=None, y=None, weights=None):
         use_teacher = self.w_kd > 0 and self.teacher is not None
         t_z = None
         if use_teacher and self._concurrent:
@@ -262,33 +286,33 @@ class DistillationStep:
                 ev.record(main)
                 self._side.wait_event(ev)
                 with torch.cuda.stream(self._side):
-                    box["t_z"] = self._teacher_forward(x, noise_teacher)
+                    box["t_z"] = self._teacher_forward(x, noise_teacher, y)
                 done = torch.cuda.Event()
                 done.record(self._side)
                 box["done"] = done
 
             eng.first_layer_hook = fork
             try:
-                s_z, s_nll, _ = self.student(x, None, noise=noise_student)
+                s_z, s_nll, _ = self.student(x, y, noise=noise_student)
             finally:
                 eng.first_layer_hook = None
             main.wait_event(box["done"])
             t_z = box["t_z"]
         else:
-            s_z, s_nll, _ = self.student(x, None, noise=noise_student)
+            s_z, s_nll, _ = self.student(x, y, noise=noise_student)
             if use_teacher:
-                t_z = self._teacher_forward(x, noise_teacher)
+                t_z = self._teacher_forward(x, noise_teacher, y)
         if use_teacher:
             return distillation_loss(s_nll, [s_z[i] for i in self.s_idx], [t_z[i] for i in self.t_idx],
-                                     self.w_nll, self.w_kd)
-        return distillation_loss(s_nll, [], [], self.w_nll, 0.0)
+                                     self.w_nll, self.w_kd, weights)
+        return distillation_loss(s_nll, [], [], self.w_nll, 0.0, weights)
 
     # A step = three phases; multi-rank graph replay captures the first and the last separately so that the
     # collective itself is never part of a captured graph.
-    def fwd_bwd(self, x, noise_student=None, noise_teacher=None, latent=None):
+    def fwd_bwd(self, x, noise_student=None, noise_teacher=None, latent=None, y_onehot=None, weights=None):
         self.flat.zero_grad()
         self.reducer.reset()
-        out = self.forward_losses(x, noise_student, noise_teacher, latent)
+        out = self.forward_losses(x, noise_student, noise_teacher, latent, y_onehot, weights)
         out["result_loss"].backward()
         return {k: v.detach() for k, v in out.items()}
 
@@ -303,10 +327,12 @@ class DistillationStep:
         eng = self.student.flow.engine()
         eng.grad_hook = (lambda idx: self.reducer.ready(self.flat.lo_for_layer(idx))) if (on and self.world > 1) else None
 
-    def training_step(self, x, noise_student=None, noise_teacher=None, latent=None):
+    def training_step(self, x, noise_student=None, noise_teacher=None, latent=None, y_onehot=None, weights=None):
         """x: [B_local, C, H, W] on the GPU (mutated in place by the dequantisation noise, as upstream), or [B, d] rows.
-        latent: optional caller-drawn latent of the perceptual branch (tests); default = a draw from the student prior."""
-        out = self.fwd_bwd(x, noise_student, noise_teacher, latent)
+        latent: optional caller-drawn latent of the perceptual branch (tests); default = a draw from the student prior.
+        y_onehot: the batch's condition (required iff the student has y_condition; pl_module.py:216-243).
+        weights: optional per-sample loss weights (the `drop_weights` data sets, pl_module.py:309-310)."""
+        out = self.fwd_bwd(x, noise_student, noise_teacher, latent, y_onehot, weights)
         self.allreduce()
         self.optimize()
         return out
@@ -322,12 +348,19 @@ class CapturedStep:
       * one rank : ONE graph = zero-grad + student fwd + teacher fwd + losses + backward + clip + Adam
       * N ranks  : graph A (zero-grad .. backward)  ->  eager bucketed RCCL all-reduce of the flat gradient
                    arena  ->  graph B (clip + Adam).  No collective is ever captured.
-    Falls back to eager execution if capture fails.
+    Falls back to eager execution (with a warning) if capture fails, unless `strict`; `self.graph is not None` tells
+    which of the two is running.
     """
 
-    def __init__(self, step, example_x, warmup=2, with_noise=False):
+    def __init__(self, step, example_x, warmup=2, with_noise=False, example_y=None, example_weights=None, strict=False):
         self.step = step
+        self.strict = strict    # True: a failed capture raises instead of degrading to eager execution
         self.static_x = example_x.clone()
+        # condition / per-sample weights of the batch (conditional students, weighted data sets): static buffers too
+        self.static_y = None if example_y is None else example_y.clone()
+        self.static_w = None if example_weights is None else example_weights.clone()
+        if self.static_y is None and getattr(step.student, "y_condition", False):
+            raise ValueError("the student is conditional (y_condition): CapturedStep needs example_y")
         # optional caller-supplied dequantisation noise (parity tests); otherwise drawn on the device inside the graph
         self.static_ns = torch.zeros_like(example_x) if with_noise else None
         self.static_nt = torch.zeros_like(example_x) if with_noise else None
@@ -342,10 +375,10 @@ class CapturedStep:
     def prepare(self):
         """Run the eager warm-up steps and capture now (so that no timed step pays for it)."""
         while self.enabled and self.graph is None:
-            self.training_step(self.static_x.clone(), *([self.static_ns, self.static_nt] if self.static_ns is not None else []))
+            self.training_step(self.static_x.clone(), self.static_ns, self.static_nt, self.static_y, self.static_w)
 
     def _eager(self):
-        return self.step.training_step(self.static_x, self.static_ns, self.static_nt)
+        return self.step.training_step(self.static_x, self.static_ns, self.static_nt, None, self.static_y, self.static_w)
 
     def _capture(self):
         torch.cuda.synchronize()
@@ -357,7 +390,7 @@ class CapturedStep:
             return
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
-            self.out = self.step.fwd_bwd(self.static_x, self.static_ns, self.static_nt)
+            self.out = self.step.fwd_bwd(self.static_x, self.static_ns, self.static_nt, None, self.static_y, self.static_w)
         with torch.cuda.graph(gb, pool=ga.pool()):
             self.step.optimize()
         self.graph, self.graph_b = ga, gb
@@ -370,13 +403,17 @@ class CapturedStep:
             self.graph_b.replay()
         return self.out
 
-    def training_step(self, x, noise_student=None, noise_teacher=None):
+    def training_step(self, x, noise_student=None, noise_teacher=None, y_onehot=None, weights=None):
         if not self.enabled:
-            return self.step.training_step(x, noise_student, noise_teacher)
+            return self.step.training_step(x, noise_student, noise_teacher, None, y_onehot, weights)
         self.static_x.copy_(x)
-        if self.static_ns is not None:
+        if self.static_ns is not None and noise_student is not self.static_ns:
             self.static_ns.copy_(noise_student)
             self.static_nt.copy_(noise_teacher)
+        if self.static_y is not None and y_onehot is not self.static_y:
+            self.static_y.copy_(y_onehot)
+        if self.static_w is not None and weights is not self.static_w:
+            self.static_w.copy_(weights)
         if self.graph is None:
             if self._warm > 0:
                 self._warm -= 1
@@ -385,6 +422,8 @@ class CapturedStep:
                 self._capture()
                 return self._replay()   # capturing does not execute: run the step it describes
             except Exception as exc:  # pragma: no cover - depends on the runtime
+                if self.strict:
+                    raise
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({exc!r}); running eagerly")
                 self.enabled = False
@@ -392,5 +431,5 @@ class CapturedStep:
                 if self.split:
                     self.step.set_allreduce_overlap(True)
                 torch.cuda.synchronize()
-                return self.step.training_step(x, noise_student, noise_teacher)
+                return self.step.training_step(x, noise_student, noise_teacher, None, y_onehot, weights)
         return self._replay()
