@@ -69,11 +69,17 @@ typedef struct nfk_step2d {
   /* bf16 mode, optional (NULL = absent): the forward weights once more in MFMA-fragment order, so that a wave
    * fetches every A operand as 1 KiB of contiguous bytes (nfk_repack_desc.wf; used by nfk_step2d_fwd_fused) */
   const void *wf1, *wf2, *wf3;
+  /* ... and the DGRAD weights in MFMA-fragment order (nfk_repack_desc.wg; used by the fused step backward,
+   * csrc/nfk_fusedb.hip): wg3 / wg2 = 32x32x16 A fragments of wd3 [hidden][Kp(9 Cout)] / wd2 [hidden][hidden],
+   * wg1 = 16x16x32 A fragments of wd1 [C/2 rounded up to 16][9 hidden] */
+  const void *wg1, *wg2, *wg3;
 } nfk_step2d;
 
-typedef struct nfk_step2d_grads {   /* all accumulate (+=) */
+typedef struct nfk_step2d_grads {   /* per-call pointers of a step backward; the gradients all accumulate (+=) */
   float *g_w1, *g_b1, *g_l1, *g_w2, *g_b2, *g_l2, *g_w3, *g_bias3, *g_l3;
   float *mix_part;                  /* [nfk_chanmix_blocks(M, C)][C*C + C], consumed by nfk_prep_bwd */
+  const void *relu_masks;           /* what nfk_step2d_fwd_fused left in `masksave` for this step, or NULL (the fused
+                                     * step backward needs them; without, the step runs the per-conv launches) */
 } nfk_step2d_grads;
 
 /* Split2d (models/layers.py:293-313): Conv2dZeros(C/2 -> C) prior on the dropped half. */
@@ -106,6 +112,9 @@ typedef struct nfk_repack_desc {
   int32_t frag;   /* layout of wf: 1 = 32x32x16 A fragments [Cout/32][Kp/16][64 lanes][8], Cout % 32 == 0;
                    *               2 = 16x16x32 A fragments [ceil(Cout/16)][Kp/32][64 lanes][8], zero rows behind Cout */
   void *wf;       /* bf16 repack only, may be NULL: fragment-ordered copy of wt (Kp = nfk_padded_k_bf16(taps*Cin)) */
+  void *wg;       /* bf16 repack only, may be NULL: fragment-ordered copy of wd (rows = Cin, Kp = nfk_padded_k_bf16(taps*Cout)),
+                   * layout `gfrag` as `frag`; for gfrag = 2 the rows behind Cin are NOT written (keep the buffer zeroed) */
+  int32_t gfrag, pad_;
 } nfk_repack_desc;
 
 typedef struct nfk_small_grad_args {
@@ -223,8 +232,16 @@ size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d *s);
 int nfk_aux_join(void *stream);
 /* bf16 backward: run a conv's dgrad GEMM and its weight-gradient GEMM as ONE launch (no second stream, no fork/join
  * edges in a captured graph).  0 = never, 1 = for steps of at most 4096 pixels (the small launches of the deep levels),
- * 2 = always (default).  Steps that use it ignore the auxiliary stream. */
+ * 2 = always.  3 (default) = as 2, and where the geometry of nfk_step2d_fwd_fused applies the whole dgrad chain of the
+ * step (dgrad3 -> ReLU/ActNorm backward -> dgrad2 -> ... -> dgrad1) is ONE launch that keeps the 512-wide gradients in LDS
+ * (csrc/nfk_fusedb.hip), followed by ONE launch for the step's three weight-gradient GEMMs.  Steps that use 1-3 ignore
+ * the auxiliary stream. */
 void nfk_set_bwd_mode(int mode);
+/* 1 if nfk_step2d_bwd* would run this step through the fused backward (needs s->wg1..3 and relu_masks), else 0 */
+int nfk_step2d_fused_bwd_ok(const nfk_step2d *s);
+size_t nfk_step2d_mask_bytes(const nfk_step2d *s);   /* size of nfk_step2d_fwd_fused's masksave */
+/* diagnostic: device buffer [workgroups][16] of shader-clock stamps per phase of the fused backward (NULL = off) */
+void nfk_fused_bwd_set_stamps(void *buf);
 void *nfk_get_aux_stream(void);
 /* Fused forward of one FlowStep in ONE launch (bf16 mode, 64-pixel row tiles; see csrc/nfk_fused.hip).
  * nfk_step2d_fused_tiles: 0 if this step's geometry is not supported (use nfk_step2d_fwd), else the number of
@@ -236,7 +253,9 @@ int nfk_step2d_fused_tiles(const nfk_step2d *s);
 void nfk_fused_set_stamps(void *buf);
 void nfk_fused_set_debug(int bits); /* diagnostic bisect of the fused kernel (results become wrong); 0 = off */
 int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zsave, void *h1save, void *h2save,
-                         float *hsave, float *zout, float *ldpart, float *ws, void *stream);
+                         float *hsave, float *zout, float *ldpart, float *ws, void *masksave, void *stream);
+/* masksave (optional, with h1save / h2save): [2][M][hidden/8] bytes, bit c%8 of byte [k][m][c/8] = (h_{k+1}[m][c] > 0), the
+ * ReLU masks of the two hidden activations -- all the fused step backward needs of them (`masks` of nfk_step2d_bwd*). */
 /* ws: nfk_step2d_fused_ws_floats(s) floats (0 for most steps).  Non-zero means the step runs "hidden split": grids that
  * would fill only 16-64 CUs give every pixel tile to 4 workgroups, each with a quarter of conv2/conv3, partial sums in
  * ws, finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows.  Passing ws == NULL
@@ -327,7 +346,10 @@ enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW
        /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode): 9 classes = conv (block.4, .2, .0) x size bucket
         * (M >= 8192, >= 2048, smaller: CIFAR levels 1 / 2 / 3 at B = 64), one template instance each for Glow's shapes */
        NFK_PROF_DUAL_BWD = 8,
-       NFK_PROF_CLASSES = 17 };
+       /* fused step backward (nfk_set_bwd_mode(3), default in bf16 mode where the geometry allows): the dgrad chain of a
+        * FlowStep in one launch (3 classes by size bucket as above) and its three weight-gradient GEMMs in one launch */
+       NFK_PROF_FUSED_BWD = 17, NFK_PROF_TRIPLE_WGRAD = 20,
+       NFK_PROF_CLASSES = 23 };
 void nfk_profile_begin(void);
 /* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
  * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */

@@ -47,12 +47,13 @@ class Step2d(C.Structure):
                 ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp),
                 ("es1", c_fp), ("es2", c_fp), ("es3", c_fp),
                 ("wt1", c_fp), ("wt2", c_fp), ("wt3", c_fp), ("wd1", c_fp), ("wd2", c_fp), ("wd3", c_fp),
-                ("wf1", c_fp), ("wf2", c_fp), ("wf3", c_fp)]
+                ("wf1", c_fp), ("wf2", c_fp), ("wf3", c_fp), ("wg1", c_fp), ("wg2", c_fp), ("wg3", c_fp)]
 
 
 class Step2dGrads(C.Structure):
     _fields_ = [("g_w1", c_fp), ("g_b1", c_fp), ("g_l1", c_fp), ("g_w2", c_fp), ("g_b2", c_fp),
-                ("g_l2", c_fp), ("g_w3", c_fp), ("g_bias3", c_fp), ("g_l3", c_fp), ("mix_part", c_fp)]
+                ("g_l2", c_fp), ("g_w3", c_fp), ("g_bias3", c_fp), ("g_l3", c_fp), ("mix_part", c_fp),
+                ("relu_masks", c_fp)]
 
 
 class Step2dNext(C.Structure):
@@ -89,7 +90,8 @@ class KdGrads(C.Structure):
 
 class RepackDesc(C.Structure):
     _fields_ = [("w", c_fp), ("wt", c_fp), ("wd", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
-                ("taps", C.c_int32), ("frag", C.c_int32), ("wf", c_fp)]
+                ("taps", C.c_int32), ("frag", C.c_int32), ("wf", c_fp), ("wg", c_fp), ("gfrag", C.c_int32),
+                ("pad_", C.c_int32)]
 
 
 i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long
@@ -137,11 +139,14 @@ _PROTOS = {
     "nfk_aux_join": (i32, [vp]),
     "nfk_set_bwd_mode": (None, [i32]),
     "nfk_get_aux_stream": (vp, []),
+    "nfk_step2d_fused_bwd_ok": (i32, [C.POINTER(Step2d)]),
+    "nfk_fused_bwd_set_stamps": (None, [vp]),
+    "nfk_step2d_mask_bytes": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_fused_tiles": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_set_stamps": (None, [vp]),
     "nfk_fused_set_debug": (None, [i32]),
     "nfk_fused_set_split": (None, [i32]),
-    "nfk_step2d_fwd_fused": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_step2d_fwd_fused": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_step2d_fused_ws_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_ld_finish": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nfk_split2d_fwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp]),
@@ -189,7 +194,10 @@ PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2
                 ) + tuple(f"dual_dgrad_wgrad_bf16_kernel {conv}, {lvl}"
                           for conv in ("conv3 (block.4: wide dgrad + narrow wgrad)", "conv2 (block.2: 512x512)",
                                        "conv1 (block.0: narrow dgrad + wide wgrad)")
-                          for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)"))
+                          for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)")) \
+    + tuple(f"{k}, {lvl}" for k in ("fusedb_step_bwd_kernel (FlowStep backward: dgrad3 -> dgrad2 -> dgrad1 in one launch)",
+                                    "triple_wgrad_bf16_kernel (the step's three weight-gradient GEMMs in one launch)")
+            for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)"))
 
 
 # class -> rocprofv3 symbol of the instance the student's chain launches at CIFAR B=64 (tools/pmc_traffic.py, bench.py `traffic`)

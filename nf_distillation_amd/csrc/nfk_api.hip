@@ -30,6 +30,9 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   // column-sum partials of the two dgrad epilogues: one row pair per m-block of THAT launch's tiling
   w.mb2 = s->bf16 ? conv_mblocks_bf16((int)M, hid, 9 * s->Cout) : conv_mblocks((int)M, hid);   // conv3 dgrad -> col2
   w.mb1 = s->bf16 ? conv_mblocks_bf16((int)M, hid, hid) : conv_mblocks((int)M, hid);           // conv2 dgrad -> col1
+  const int fg = (s->bf16 && fusedb_grid(*s) > 0) ? actnorm_sum_parts((int)M) : 0;   // the fused backward's partial rows
+  if (fg > w.mb2) w.mb2 = fg;
+  if (fg > w.mb1) w.mb1 = fg;
   size_t o = 0;
   w.ga3 = o; o += align4(M * s->Cout);
   w.gz = o; o += align4(M * s->C);
@@ -66,7 +69,8 @@ int splitk_of(int bf16, int M, int N, int K) {
 // Optional auxiliary stream: when set, the weight-gradient GEMMs of a step's backward run on it,
 // concurrently with the dgrad chain on the caller's stream (fork/join with events; capturable).
 static hipStream_t g_aux = nullptr;
-static int g_bwd_mode = 2;
+static int g_bwd_mode = 3;
+static unsigned long long* g_bwd_stamps = nullptr;   // diagnostic (nfk_fused_bwd_set_stamps)
 static hipEvent_t g_ev[4];
 static bool g_ev_ready = false;
 static bool g_aux_forked = false;   // work was sent to the auxiliary stream since the last join
@@ -277,7 +281,9 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   // Each conv's weight gradient (slabs -> finalize) and dgrad read the same output gradient and are independent.
   // bf16 "dual" mode runs the two GEMMs as ONE launch on the caller's stream; otherwise the weight gradient goes to
   // the auxiliary stream (if one is set), forked here and joined at the end of the call / by nfk_aux_join.
-  const bool dual = bf && (g_bwd_mode == 2 || (g_bwd_mode == 1 && M <= 4096));
+  const bool dual = bf && (g_bwd_mode >= 2 || (g_bwd_mode == 1 && M <= 4096));
+  // fused backward: needs the ReLU masks the fused forward leaves (g->relu_masks) and a supported geometry
+  const int fgrid = (bf && g_bwd_mode == 3 && g->relu_masks) ? fusedb_grid(*s) : 0;
   hipStream_t ws_st = st;  // stream of the wgrad GEMMs
   const bool use_aux = !dual && g_aux && g_aux != st;
   if (use_aux) ws_st = g_aux;
@@ -300,6 +306,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
     return run_conv(bf, dg, st);
   };
 
+  int mb1 = L.mb1, mb2 = L.mb2;
   // conv3 (block.4)
   WgradArgs w3{};
   w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
@@ -307,7 +314,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   w3.qbf16 = bf;
   ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD, bf, 1, bf);
   d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
-  NFK_TRY(conv_bwd(d3, w3, L.S3w, Cout, hid, 9, g->g_w3));
+  if (!fgrid) NFK_TRY(conv_bwd(d3, w3, L.S3w, Cout, hid, 9, g->g_w3));
 
   // conv2 (block.2)
   WgradArgs w2{};
@@ -316,7 +323,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   w2.pbf16 = bf; w2.qbf16 = bf;
   ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
   d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
-  NFK_TRY(conv_bwd(d2, w2, L.S2w, hid, hid, 1, g->g_w2));
+  if (!fgrid) NFK_TRY(conv_bwd(d2, w2, L.S2w, hid, hid, 1, g->g_w2));
 
   // conv1 (block.0)
   WgradArgs w1{};
@@ -324,10 +331,30 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   w1.B = B; w1.H = H; w1.W = W; w1.out = wslab + L.ws3 + L.ws2; w1.slab_stride = (long)hid * 9 * Ch;
   w1.pbf16 = bf;
   ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
-  NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
+  if (!fgrid) NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
+  if (fgrid) {
+    // fused backward: the whole dgrad chain in one launch (g_a2 / g_a1 stay in LDS between the convolutions and are
+    // written once for the weight gradients), then the three weight-gradient GEMMs in one launch
+    FusedBwdCall fc{};
+    fc.s = *s; fc.ga3 = ga3; fc.masks = reinterpret_cast<const unsigned char*>(g->relu_masks);
+    fc.ga2 = ga2; fc.ga1 = ga1; fc.d1 = d1; fc.stamps = g_bwd_stamps;
+    NFK_TRY(fusedb_launch(fc, st));
+    ActnormSumArgs an{};
+    an.ga2 = ga2; an.h2 = h2; an.ga1 = ga1; an.h1 = h1; an.es2 = s->es2; an.es1 = s->es1; an.col2 = col2; an.col1 = col1;
+    an.M = M; an.hid = hid; an.nparts = actnorm_sum_parts(M);
+    mb1 = mb2 = an.nparts;
+    NFK_TRY(triple_wgrad_bf16(w3, L.S3w, w2, L.S2w, w1, L.S1w, an, st));
+    const WgradArgs* ws3[3] = {&w3, &w2, &w1};
+    const int Sw[3] = {L.S3w, L.S2w, L.S1w}, Co[3] = {Cout, hid, hid}, Ci[3] = {hid, hid, Ch}, tp[3] = {9, 1, 9};
+    float* gw[3] = {g->g_w3, g->g_w2, g->g_w1};
+    for (int k = 0; k < 3; ++k) {
+      tail_f.slabs[k] = ws3[k]->out; tail_f.gradW[k] = gw[k]; tail_f.stride[k] = ws3[k]->slab_stride;
+      tail_f.S[k] = Sw[k]; tail_f.Cout[k] = Co[k]; tail_f.Cin[k] = Ci[k]; tail_f.taps[k] = tp[k];
+    }
+  }
 
   nfk_small_grad_args sg{};
-  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb1; sg.mb2 = L.mb2;
+  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = mb1; sg.mb2 = mb2;
   sg.B = coupling_rows > 0 ? coupling_rows : B;
   sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
@@ -338,7 +365,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   ChanMixArgs m{};
   m.x = gz; m.ldx = C; m.Wm = s->Wf; m.cv = nullptr; m.z = g_x; m.ldz = C; m.M = M; m.C = C; m.trans = 1;
   // conv1's dgrad leaves L.S1 split-K slabs -- or one, when the dual launch ran it through the halo-tile kernel
-  const int S1_used = (dual && narrow_halo_dgrad_active(bf, M, H, W, Ch, hid)) ? 1 : L.S1;
+  const int S1_used = (fgrid || (dual && narrow_halo_dgrad_active(bf, M, H, W, Ch, hid))) ? 1 : L.S1;
   m.ga = g_out; m.lda = C; m.gext = g_ext; m.ldge = C; m.slab = d1; m.S = S1_used; m.slab_stride = (long)M * Ch;
   m.Ch = Ch; m.xin = x; m.ldxin = ldx; m.part = g->mix_part;
   // dual mode: the step tail (slab reductions + per-channel gradients) and this channel mix share one launch
@@ -400,6 +427,9 @@ size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d* s) {
   return L.total - L.wslab;
 }
 void* nfk_get_aux_stream(void) { return g_aux; }
+void nfk_fused_bwd_set_stamps(void* buf) { g_bwd_stamps = reinterpret_cast<unsigned long long*>(buf); }
+int nfk_step2d_fused_bwd_ok(const nfk_step2d* s) { return (s->bf16 && g_bwd_mode == 3 && fusedb_grid(*s) > 0) ? 1 : 0; }
+size_t nfk_step2d_mask_bytes(const nfk_step2d* s) { return (size_t)2 * s->B * s->H * s->W * (s->hidden / 8); }
 void nfk_set_bwd_mode(int mode) { g_bwd_mode = mode; }
 int nfk_aux_join(void* stream) {
   hipStream_t st = S_(stream);

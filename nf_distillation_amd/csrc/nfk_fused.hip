@@ -555,12 +555,13 @@ int nfk_step2d_fused_tiles(const nfk_step2d* s) {
 }
 
 static int step2d_fwd_fused_impl(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save,
-                                 void* h2save, float* hsave, float* zout, float* ldpart, float* ws, void* stream);
+                                 void* h2save, float* hsave, float* zout, float* ldpart, float* ws, void* masksave,
+                                 void* stream);
 
 size_t nfk_step2d_fused_ws_floats(const nfk_step2d* s) { return v2_tiles(*s) ? fused2_ws_floats(*s) : 0; }
 
 int nfk_step2d_fwd_fused(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save, void* h2save,
-                         float* hsave, float* zout, float* ldpart, float* ws, void* stream) {
+                         float* hsave, float* zout, float* ldpart, float* ws, void* masksave, void* stream) {
   // algorithmic work of one FlowStep forward (bench.py roofline leg): the three convs' FLOPs; HBM bytes = the step's
   // input and output, its bf16 weights once, and what a training forward keeps for the backward
   const double M = (double)s->B * s->H * s->W, hid = s->hidden, K1 = 9.0 * (s->C / 2);
@@ -574,16 +575,19 @@ int nfk_step2d_fwd_fused(const nfk_step2d* s, const float* x, int ldx, float* zs
   int cls = NFK_PROF_FUSED_STEP + (s->Cout + 15) / 16 - 1;
   if (cls > NFK_PROF_FUSED_STEP_NT3) cls = NFK_PROF_FUSED_STEP_NT3;
   prof_scope_begin(cls, flops, bytes, st);
-  const int rc = step2d_fwd_fused_impl(s, x, ldx, zsave, h1save, h2save, hsave, zout, ldpart, ws, stream);
+  const int rc = step2d_fwd_fused_impl(s, x, ldx, zsave, h1save, h2save, hsave, zout, ldpart, ws, masksave, stream);
   prof_scope_end(cls, st);
   return rc;
 }
 
 static int step2d_fwd_fused_impl(const nfk_step2d* s, const float* x, int ldx, float* zsave, void* h1save,
-                                 void* h2save, float* hsave, float* zout, float* ldpart, float* ws, void* stream) {
+                                 void* h2save, float* hsave, float* zout, float* ldpart, float* ws, void* masksave,
+                                 void* stream) {
+  if (masksave && !(v2_tiles(*s) && h1save && h2save)) return NFK_ERR_ARG;   // only the generation-2 kernel writes masks
   if (v2_tiles(*s)) {
     FusedCall c{};
     c.s = *s; c.x = x; c.ldx = ldx; c.zsave = zsave; c.h1save = h1save; c.h2save = h2save; c.hsave = hsave;
+    c.masksave = reinterpret_cast<unsigned char*>(masksave);
     c.zout = zout; c.ldpart = ldpart; c.ws = ws; c.stamps = g_stamps; c.dbg = g_dbg;
     return fused2_launch(c, reinterpret_cast<hipStream_t>(stream));
   }

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   }
   // coalesced copy of the 64 output pixels' rows (16-byte slots slot0 .. slot0 + 2^slots_log2 - 1) of the LDS image to
   // columns col0.. of a global [M][512] bf16 array
-  auto save_rows = [&](__bf16* dstg, int col0, const char* img, int slots_log2, int slot0) {
+  // `mask` (optional): [M][HID/8] bytes, bit c%8 of byte c/8 = (h[m][c] > 0) -- what the fused step backward needs of h
+  auto save_rows = [&](__bf16* dstg, int col0, const char* img, int slots_log2, int slot0, unsigned char* mask) {
     const int spr = 1 << slots_log2;                 // 16-byte slots per row
     const int slot = tid & (spr - 1);
     for (int po = tid >> slots_log2; po < 64; po += (256 >> slots_log2)) {
@@ -287,6 +288,13 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       const long m = (long)b * HW + (row0 + rr) * W + xx;
       const u32x4f v = *reinterpret_cast<const u32x4f*>(img + f2_h1_off(ph, slot0 + slot));
       *reinterpret_cast<u32x4f*>(dstg + m * HID + col0 + slot * 8) = v;
+      if (mask) {   // post-ReLU bf16 values are >= +0: positive <=> non-zero bits
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          bits |= ((v[e] & 0xFFFFu) ? 1u : 0u) << (2 * e) | ((v[e] >> 16) ? 1u : 0u) << (2 * e + 1);
+        mask[m * (HID / 8) + (col0 >> 3) + slot] = (unsigned char)bits;
+      }
     }
   };
 
@@ -371,7 +379,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     }
   }
   __syncthreads();
-  if (a.c.h1save && qs == 0) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, 0);
+  if (a.c.h1save && qs == 0) save_rows(reinterpret_cast<__bf16*>(a.c.h1save), 0, H1, 6, 0, a.c.masksave);
   stamp(3);
 
   // ------------------------------------------------------------------ 4. conv2: ONE pass over k for all of the wave's channel tiles
@@ -458,9 +466,10 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   }
   __syncthreads();
   if (a.c.h2save) {
-    if (NCH == 4) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), 0, H1, 6, 0);
+    unsigned char* m2 = a.c.masksave ? a.c.masksave + (long)s.B * HW * (HID / 8) : nullptr;
+    if (NCH == 4) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), 0, H1, 6, 0, m2);
     else
-      for (int i = 0; i < NCH; ++i) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), (nc0 + i) * 128, H1, 4, (nc0 + i) * 16);
+      for (int i = 0; i < NCH; ++i) save_rows(reinterpret_cast<__bf16*>(a.c.h2save), (nc0 + i) * 128, H1, 4, (nc0 + i) * 16, m2);
   }
 
   // ------------------------------------------------------------------ 5. conv3 over the wave's K-slices of h2

@@ -1,0 +1,516 @@
+// nfk fused FlowStep BACKWARD (bf16 operands / fp32 accumulate): the dgrad chain of a step in ONE launch
+// (autograd of models/flows.py:142-171 through the coupling net of models/flows.py:25-34):
+//
+//     g_a3 [M][Cout] --dgrad3 (3x3, Cout->512)--> g_h2 --ReLU/ActNorm bwd--> g_a2
+//          --dgrad2 (1x1, 512->512)--> g_h1 --ReLU/ActNorm bwd--> g_a1 --dgrad1 (3x3, 512->C/2)--> g_z1
+//
+// It is the mirror image of the fused forward (nfk_fused2.hip), with the same pixel tiles, the same LDS image and the
+// same weight streaming; a transposed 3x3 convolution is a 3x3 convolution with flipped taps (the `wd` layouts), so
+//   1. stage    the tile's rows (+2 halo rows each side) of g_a3 (fp32), 3x3 im2col -> bf16 tile      (forward: mix + im2col)
+//   2. dgrad3   [512 x 9 Cout] x im2col, 32x32x16 MFMA, weights in registers                           (forward: conv1)
+//               epilogue: g_a2 = (h2 > 0) ? g * e^logs2 : 0  -> the LDS image (bf16)
+//   3. dgrad2   [512 x 512] x image in ONE pass over k, 12 accumulator tiles per wave, W2^T streamed   (forward: conv2)
+//               from L2 through a register ring; g_a1 = (h1 > 0) ? g * e^logs1 : 0 then REPLACES g_a2 in the image
+//   4. dgrad1   [C/2 x 9*512] x shifted rows of the image, 16x16x32 MFMA, K split over the waves       (forward: conv3)
+//   g_a2 / g_a1 leave LDS once, as the rows of the tile's own 64 pixels (bf16): the weight-gradient GEMMs read them.
+// Of the saved activations h1 / h2 the chain needs only the ReLU masks: the fused forward leaves them as one bit per
+// element (FusedCall.masksave, 1/16 of the bf16 tensors), so this kernel reads g_a3, 2 x 6 KB of mask words and the
+// weights -- no 512-wide tensor at all.  The per-channel sums behind the two ActNorm layers' gradients
+// (sum g_a h / e^logs, sum g_a) are taken where g_a and h are both streamed anyway: beside the weight-gradient GEMMs
+// (actnorm_sum_body in nfk_gemm_bf16.hip).
+// What this replaces per step: three GEMM launches whose 512-wide operands (g_a2, g_a1: 16.8 MB each at CIFAR level 1,
+// B = 64) made a round trip through HBM each, re-read once per tap by the narrow dgrad, plus the 2 x 16.8 MB of h1 / h2
+// their epilogues read.
+#include "nfk_internal.h"
+
+namespace nfk {
+
+typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4f __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
+
+struct FBArgs {
+  FusedBwdCall c;
+  int R, TS, halo;       // rows per tile, samples per tile, 1 if the tile needs halo rows
+  int lw, lrw, lhw;      // log2(W), log2(R*W), log2(RH*W) (the last only meaningful when TS > 1)
+};
+
+struct FBGeom {
+  int RH, RZ, P_h, MT32, K3, K3M, K3p, X3S, NTD;
+  size_t oG3, oPar, oX3, oImg, oZero, total;
+};
+
+__host__ __device__ static inline FBGeom fb_geom(const nfk_step2d& s, int R, int TS, int halo) {
+  FBGeom g;
+  const int W = s.W, Ch = s.C / 2;
+  g.RH = R + 2 * halo;
+  g.RZ = R + 4 * halo;
+  g.P_h = TS * g.RH * W;
+  g.MT32 = (g.P_h + 31) / 32;
+  g.K3 = 9 * s.Cout;
+  g.K3p = (g.K3 + 63) / 64 * 64;                     // = the k extent of wd3 / wg3 (nfk_padded_k_bf16)
+  g.K3M = g.K3p / 16;                                // dgrad3 k-steps of 16 (zero columns pad the im2col tile)
+  g.X3S = g.K3p * 2 + 16;                            // bytes per im2col row: an odd number of 16-byte slots
+  g.NTD = (Ch + 15) / 16;
+  size_t o = 0;
+  g.oG3 = o; o += (size_t)TS * g.RZ * W * s.Cout * 4;
+  o = (o + 15) & ~size_t(15);
+  g.oPar = o; o += (size_t)2 * s.hidden * 4;
+  g.oX3 = o; o += (size_t)g.MT32 * 32 * g.X3S;
+  o = (o + 15) & ~size_t(15);
+  g.oImg = o; o += (size_t)g.MT32 * 32 * 1024;
+  g.oZero = o; o += 3 * 256 + 16;   // sixteen zero bytes per 128-channel chunk, 256 bytes apart (see nfk_fused2.hip)
+  g.total = o;
+  return g;
+}
+
+__device__ __forceinline__ unsigned fb_pack(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fb_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8f fb_ldw(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// image: 1024-byte rows (512 channels); the low 4 bits of the 16-byte slot index are XORed with the pixel index
+__device__ __forceinline__ int fb_img_off(int px, int slot) {
+  return px * 1024 + ((((slot ^ px) & 15) | (slot & ~15)) << 4);
+}
+
+template <int MT32, int NTD, int K3M>
+__global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
+  constexpr int HID = 512;
+  constexpr int MT_O = 4;   // 64 output pixels = 4 tiles of 16 (dgrad1 uses 16x16x32)
+  extern __shared__ __attribute__((aligned(16))) char smem_fb[];
+  const nfk_step2d& s = a.c.s;
+  const int W = s.W, H = s.H, Ch = s.C / 2, Cout = s.Cout, HW = H * W;
+  const int R = a.R, TS = a.TS, halo = a.halo, lw = a.lw, lrw = a.lrw, lhw = a.lhw;
+  const FBGeom g = fb_geom(s, R, TS, halo);
+  float* G3 = reinterpret_cast<float*>(smem_fb + g.oG3);
+  float* Pe2 = reinterpret_cast<float*>(smem_fb + g.oPar);
+  float* Pe1 = Pe2 + HID;
+  char* X3 = smem_fb + g.oX3;
+  char* IMG = smem_fb + g.oImg;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l32 = lane & 31, hi = lane >> 5;      // 32x32x16 operand roles: row / k-half
+  const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 operand roles (dgrad1)
+
+  const int tps = (TS == 1) ? H / R : 1;
+  const int wg = (int)blockIdx.x;
+  const int b0 = (TS == 1) ? wg / tps : wg * TS;
+  const int tile = (TS == 1) ? wg - b0 * tps : 0;
+  const int row0 = tile * R;
+  const int zh = 2 * halo;
+  auto stamp = [&](int i) {
+    if (a.c.stamps && tid == 0) a.c.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
+  };
+  stamp(0);
+
+  // ------------------------------------------------------------------ 0. dgrad3's weights -> registers (in flight during 1.)
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+  const int voffL = lane * 16;
+  constexpr int W3R = (K3M >= 28) ? 1 : ((K3M >= 16) ? 2 : 4);   // register ring: tiles of 32 output channels held ahead
+                                                                  // (1: every fragment is reloaded in place right after its use)
+  bf16x8f w3[W3R][K3M];
+  const __amdgpu_buffer_rsrc_t r3 = fb_rsrc(s.wg3, (unsigned)HID * g.K3p * 2);
+  auto load_w3 = [&](int j, bf16x8f (&f)[K3M]) {   // row tile (32 channels) swid*4 + j
+    const int soff = (swid * 4 + j) * K3M * 1024;
+#pragma unroll
+    for (int ks = 0; ks < K3M; ++ks) f[ks] = fb_ldw(r3, voffL, soff + ks * 1024);
+  };
+
+  // rows of the LDS image -> rows of a global [M][512] bf16 array, for the tile's own 64 pixels; 16-byte pieces, a
+  // row's 64 pieces by consecutive threads
+  auto save_rows = [&](__bf16* dstg) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int p = tid + 256 * it, po = p >> 6, slot = p & 63;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+      const int b = b0 + sm;
+      if (b >= s.B) continue;
+      const int ph = sm * g.RH * W + (rr + halo) * W + xx;
+      const long m = (long)b * HW + (row0 + rr) * W + xx;
+      *reinterpret_cast<u32x4f*>(dstg + m * HID + slot * 8) = *reinterpret_cast<const u32x4f*>(IMG + fb_img_off(ph, slot));
+    }
+  };
+
+  // ------------------------------------------------------------------ 1. stage g_a3 (+2 halo rows), parameters, ReLU masks
+  // ReLU mask words of this lane's pixel in every 32-pixel tile of the h-region (zero outside the image / the batch:
+  // the gradients there are the zero padding of dgrad1): mk2[mt] = the 4 words of the wave's channel tiles in dgrad3
+  // (tiles wid*4 .. wid*4+3), mk1[mt][i] = the word of tile i*4 + wid in dgrad2.  Requested first, used in the epilogues.
+  u32x4f mk2[MT32];
+  unsigned mk1[MT32][4];
+  {
+    constexpr unsigned FB_OOB = 0x80000000u;
+    const long msz = (long)s.B * HW * (HID / 8);
+    const __amdgpu_buffer_rsrc_t rm1 = fb_rsrc(a.c.masks, (unsigned)msz), rm2 = fb_rsrc(a.c.masks + msz, (unsigned)msz);
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt) {
+      const int ph = mt * 32 + l32;
+      const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
+      const int rr = rem >> lw, xx = rem & (W - 1);
+      const int y = row0 + rr - halo, b = b0 + sm;
+      const bool ok = ph < g.P_h && (unsigned)y < (unsigned)H && b < s.B;
+      const int moff = ((b * HW + y * W + xx) * (HID / 8));
+      mk2[mt] = __builtin_amdgcn_raw_buffer_load_b128(rm2, ok ? moff + wid * 16 : (int)FB_OOB, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        mk1[mt][i] = __builtin_amdgcn_raw_buffer_load_b32(rm1, ok ? moff + (i * 4 + wid) * 4 : (int)FB_OOB, 0, 0);
+    }
+    constexpr int GMAX = 12;   // per-thread slots: TS*RZ*W*Cout <= 3072 (checked on the host)
+    const int rowlen = W * Cout, per_s = g.RZ * rowlen, nx = TS * per_s;
+    const int lo = (TS == 1) ? max(0, zh - row0) * rowlen : 0;                                     // elements inside the image
+    const int hi_e = (TS == 1) ? min(g.RZ, H - row0 + zh) * rowlen : min(s.B - b0, TS) * per_s;    // ... and the batch
+    const float* gb = a.c.ga3 + ((long)b0 * HW + (long)(row0 - zh) * W) * Cout;   // rows are contiguous: [pixel][Cout]
+    float greg[GMAX];
+#pragma unroll
+    for (int i = 0; i < GMAX; ++i) greg[i] = gb[min(max(tid + 256 * i, lo), hi_e - 1)];   // clamped: unconditional loads
+    const float e2a = s.es2[tid], e2b = s.es2[tid + 256], e1a = s.es1[tid], e1b = s.es1[tid + 256];
+#pragma unroll
+    for (int j = 0; j < W3R; ++j) load_w3(j, w3[j]);
+#pragma unroll
+    for (int i = 0; i < GMAX; ++i) {
+      const int e = tid + 256 * i;
+      if (e < nx) G3[e] = (e >= lo && e < hi_e) ? greg[i] : 0.f;
+    }
+    Pe2[tid] = e2a; Pe2[tid + 256] = e2b; Pe1[tid] = e1a; Pe1[tid + 256] = e1b;
+    if (tid < 16) reinterpret_cast<unsigned*>(smem_fb + g.oZero + (tid >> 2) * 256)[tid & 3] = 0u;
+  }
+  __syncthreads();
+  stamp(1);
+  // im2col of g_a3 on the h-region (bf16 pairs); k = tap * Cout + co, the order of wd3's columns
+  {
+    const int npad = (g.K3p - g.K3) >> 1;   // zero pairs behind the last tap (K3 = 9 * Cout is even)
+    for (int t = tid; t < MT32 * 32 * 10; t += 256) {
+      const int ph = (int)__umulhi((unsigned)t, 429496730u), tap = t - ph * 10;
+      char* dst = X3 + ph * g.X3S;
+      if (tap == 9) {
+        unsigned* d = reinterpret_cast<unsigned*>(dst + g.K3 * 2);
+        for (int e = 0; e < npad; ++e) d[e] = 0u;
+        continue;
+      }
+      const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
+      const int rr = rem >> lw, xx = rem & (W - 1);
+      const int t3 = (tap * 11) >> 5;               // tap / 3 for tap < 9
+      const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+      const int rz = rr + halo + dy, xn = xx + dx;  // G3 has `zh` halo rows, the h-region `halo`
+      const bool ok = ph < g.P_h && (unsigned)rz < (unsigned)g.RZ && (unsigned)xn < (unsigned)W;
+      const float* src = G3 + ((sm * g.RZ + rz) * W + xn) * Cout;
+      unsigned* d = reinterpret_cast<unsigned*>(dst + tap * Cout * 2);
+      for (int ci = 0; ci < Cout; ci += 2) d[ci >> 1] = ok ? fb_pack(src[ci], src[ci + 1]) : 0u;
+    }
+  }
+  __syncthreads();
+  stamp(2);
+
+  // ReLU / ActNorm backward of one accumulator tile (32 channels x 32 pixels per m-tile) into the image:
+  //   g_a = (h > 0) ? g e^logs : 0, bit (8*gi + 4*hi + r) of `word` = (h > 0) for channel n0 - 4*hi + 8*gi + 4*hi + r
+  // `base[mt]`: byte address of this lane's pixel row (+ 8*hi), `sw[gi]`: swizzled offset of the 4-channel group gi,
+  // n0: first channel of the tile (+ 4*hi), es: the layer's e^logs
+  auto relu_an_bwd = [&](f32x16 (&acc)[MT32], char* (&base)[MT32], const int (&sw)[4], const float* es, int n0,
+                         const unsigned (&word)[MT32]) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const f32x4 e = *reinterpret_cast<const f32x4*>(es + n0 + 8 * gi);
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt) {
+        const unsigned m4 = word[mt] >> (8 * gi + 4 * hi);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((m4 >> r) & 1u) ? acc[mt][4 * gi + r] * e[r] : 0.f;
+        const u32x2f pk = {fb_pack(v[0], v[1]), fb_pack(v[2], v[3])};
+        *reinterpret_cast<u32x2f*>(base[mt] + sw[gi]) = pk;
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------ 2. dgrad3 -> g_a2 in the image
+  const __amdgpu_buffer_rsrc_t r2 = fb_rsrc(s.wg2, (unsigned)HID * HID * 2);
+  constexpr int NCH = 4, RD = 8;             // dgrad2: channel tiles per wave, W2^T register ring (RD k-steps x NCH)
+  bf16x8f w2r[RD][NCH];
+  int w2s[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) w2s[i] = (i * 4 + swid) * (HID / 16) * 1024;
+  auto load_w2_part = [&](int part) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = part * 8 + e;
+      w2r[f / NCH][f % NCH] = fb_ldw(r2, voffL, w2s[f % NCH] + (f / NCH) * 1024);
+    }
+  };
+  {
+    const char* x3_lane = X3 + l32 * g.X3S + hi * 16;
+    char* imw[MT32];
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt) imw[mt] = IMG + (mt * 32 + l32) * 1024 + 8 * hi;
+    bf16x8f xb[2][MT32];
+    auto rd1 = [&](int ks, bf16x8f (&f)[MT32]) {
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+        f[mt] = *reinterpret_cast<const bf16x8f*>(x3_lane + mt * 32 * g.X3S + ks * 32);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x16 acc[MT32];
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      rd1(0, xb[0]);
+#pragma unroll
+      for (int ks = 0; ks < K3M; ++ks) {
+        if (ks + 1 < K3M) rd1(ks + 1, xb[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[j % W3R][ks], xb[ks & 1][mt], acc[mt], 0, 0, 0);
+        if (W3R == 1 && j + 1 < 4) w3[0][ks] = fb_ldw(r3, voffL, ((swid * 4 + j + 1) * K3M + ks) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (W3R > 1 && j + W3R < 4) load_w3(j + W3R, w3[j % W3R]);
+      load_w2_part(j);
+      // image address of channel group gi of tile (wid*4 + j): slot = wid*16 + j*4 + gi (see nfk_fused2.hip, conv1)
+      int sw[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) sw[gi] = ((((j * 4 + gi) ^ l32) & 15) << 4) + wid * 256;
+      unsigned word[MT32];
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt) word[mt] = mk2[mt][j];
+      relu_an_bwd(acc, imw, sw, Pe2, (wid * 4 + j) * 32 + 4 * hi, word);
+    }
+  }
+  __syncthreads();
+  stamp(3);
+  save_rows(reinterpret_cast<__bf16*>(a.c.ga2));
+  stamp(4);
+
+  // ------------------------------------------------------------------ 3. dgrad2: ONE pass over k (see nfk_fused2.hip, conv2)
+  const __amdgpu_buffer_rsrc_t r1 = fb_rsrc(s.wg1, (unsigned)NTD * 16 * 9 * HID * 2);
+  constexpr int Kp1 = 9 * HID;
+  constexpr int D1 = (NTD == 1 && MT32 == 2) ? 4 : 2;   // dgrad1's weight ring: chunks of 128 channels held ahead (it is
+                                                        // requested while dgrad2's 4 x MT32 accumulator tiles are live)
+  bf16x8f w1[D1][9][NTD];
+  auto load_w1 = [&](int slot, int nc, int tap) {   // k-step (of 32) tap*16 + nc*4 + swid of every row tile
+#pragma unroll
+    for (int nt = 0; nt < NTD; ++nt)
+      w1[slot][tap][nt] = fb_ldw(r1, voffL, (nt * (Kp1 / 32) + tap * 16 + nc * 4 + swid) * 1024);
+  };
+  {
+    const int pc = (l32 & 15) ^ hi;
+    const char* imr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) imr[e] = IMG + l32 * 1024 + (((2 * e) ^ pc) << 4);
+    f32x16 acc2[NCH][MT32];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][mt][r] = 0.f;
+    bf16x8f fb[2][MT32];
+    auto rd2 = [&](int ks, bf16x8f (&f)[MT32]) {
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt)
+        f[mt] = *reinterpret_cast<const bf16x8f*>(imr[ks & 7] + mt * 32768 + (ks >> 3) * 256);
+    };
+    rd2(0, fb[0]);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks + 1 < 32) rd2(ks + 1, fb[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt)
+          acc2[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[ks % RD][i], fb[ks & 1][mt], acc2[i][mt], 0, 0, 0);
+        if (ks + RD < 32) w2r[ks % RD][i] = fb_ldw(r2, voffL, w2s[i] + (ks + RD) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stamp(5);
+    // dgrad1's weight ring: requested before the epilogue (a stretch of pure VALU work), it travels under it
+#pragma unroll
+    for (int c = 0; c < D1; ++c)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) load_w1(c, c, tap);
+    __syncthreads();   // every wave is done reading g_a2: g_a1 takes its place in the image (same layout)
+    stamp(6);
+    char* imw[MT32];
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt) imw[mt] = IMG + (mt * 32 + l32) * 1024 + 8 * hi;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      // channel tile i*4 + wid: slots i*16 + wid*4 + gi  ->  byte i*256 + (((wid*4 + gi) ^ px) & 15) * 16
+      int sw[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) sw[gi] = ((((wid * 4 + gi) ^ l32) & 15) << 4) + i * 256;
+      unsigned word[MT32];
+#pragma unroll
+      for (int mt = 0; mt < MT32; ++mt) word[mt] = mk1[mt][i];
+      relu_an_bwd(acc2[i], imw, sw, Pe1, (i * 4 + wid) * 32 + 4 * hi, word);
+    }
+  }
+  __syncthreads();
+  stamp(7);
+  save_rows(reinterpret_cast<__bf16*>(a.c.ga1));
+  stamp(8);
+
+  // ------------------------------------------------------------------ 4. dgrad1 over the wave's K-slices of the g_a1 image
+  f32x4 acc1[NTD][MT_O];
+#pragma unroll
+  for (int i = 0; i < NTD; ++i)
+#pragma unroll
+    for (int j = 0; j < MT_O; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    int c_off[9][MT_O];
+    const unsigned k4 = (unsigned)(wid * 4 + q4), zoff = (unsigned)g.oZero, ioff = (unsigned)g.oImg;
+#pragma unroll
+    for (int mo = 0; mo < MT_O; ++mo) {
+      const int po = mo * 16 + r16;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = (rem >> lw) + halo, xx = rem & (W - 1);
+      const unsigned px0 = (unsigned)(sm * g.RH * W + rr * W + xx);
+      unsigned rok[3], xok[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        rok[d] = 0u - (unsigned)((unsigned)(rr + d - 1) < (unsigned)g.RH);
+        xok[d] = 0u - (unsigned)((unsigned)(xx + d - 1) < (unsigned)W);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const unsigned px = px0 + (unsigned)(dy * W + dx);
+        const unsigned addr = ioff + (px << 10) + (((k4 ^ px) & 15u) << 4);
+        c_off[tap][mo] = (int)(zoff ^ ((addr ^ zoff) & rok[dy + 1] & xok[dx + 1]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8f fb[4][MT_O];
+      auto rd3 = [&](int tap, bf16x8f (&f)[MT_O]) {
+#pragma unroll
+        for (int mo = 0; mo < MT_O; ++mo)
+          f[mo] = *reinterpret_cast<const bf16x8f*>(smem_fb + c_off[tap][mo] + i * 256);
+      };
+      rd3(0, fb[0]);
+      rd3(1, fb[1]);
+      rd3(2, fb[2]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 3 < 9) rd3(tap + 3, fb[(tap + 3) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mo = 0; mo < MT_O; ++mo)
+#pragma unroll
+          for (int nt = 0; nt < NTD; ++nt)
+            acc1[nt][mo] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i % D1][tap][nt], fb[tap & 3][mo], acc1[nt][mo], 0, 0, 0);
+        if (i + D1 < 4) load_w1(i % D1, i + D1, tap);   // in place, D1 chunks ahead
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();
+  stamp(9);
+
+  // ------------------------------------------------------------------ 5. cross-wave reduction -> g_z1 contribution [M][C/2]
+  float* R3 = reinterpret_cast<float*>(IMG);     // [4 waves][64 px][NTD*16]   (the image is dead now)
+  constexpr int NP = NTD * 16;
+#pragma unroll
+  for (int nt = 0; nt < NTD; ++nt)
+#pragma unroll
+    for (int mo = 0; mo < MT_O; ++mo)
+      *reinterpret_cast<f32x4*>(R3 + ((wid * 64 + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc1[nt][mo];
+  __syncthreads();
+  const unsigned mCh = 0xFFFFFFFFu / (unsigned)Ch + 1u;
+  for (int idx = tid; idx < 64 * Ch; idx += 256) {
+    const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
+    const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+    const int b = b0 + sm;
+    if (b >= s.B) continue;
+    const float* p = R3 + po * NP + n;
+    a.c.d1[((long)b * HW + (row0 + rr) * W + xx) * Ch + n] = (p[0] + p[64 * NP]) + (p[2 * 64 * NP] + p[3 * 64 * NP]);
+  }
+  stamp(10);
+}
+
+static int fb_ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+static bool fb_pick(const nfk_step2d& s, FBArgs* a) {
+  if (!s.bf16 || s.hidden != 512 || s.Cout > 48 || s.Cout < 2 || (s.Cout & 1) || (s.C & 3) != 0 || s.C < 4) return false;
+  if (!s.wg1 || !s.wg2 || !s.wg3) return false;   // needs the fragment-ordered dgrad weights
+  const int lw = fb_ilog2_exact(s.W), lh = fb_ilog2_exact(s.H);
+  if (lw < 0 || lh < 0) return false;
+  const int HW = s.H * s.W;
+  if (HW <= 64) { a->R = s.H; a->TS = 64 / HW; a->halo = 0; }
+  else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) { a->R = 64 / s.W; a->TS = 1; a->halo = 1; }
+  else return false;
+  const FBGeom g = fb_geom(s, a->R, a->TS, a->halo);
+  if (g.MT32 != 2 && g.MT32 != 3) return false;
+  if (g.total > 160 * 1024 - 512) return false;
+  if ((size_t)4 * 64 * g.NTD * 16 * 4 > (size_t)g.MT32 * 32 * 1024) return false;   // R3 lives in the image
+  if (a->TS * g.RZ * s.W * s.Cout > 12 * 256) return false;                          // prologue register slots
+  if ((long)s.B * HW * 64 >= 0x7fffffffL) return false;                              // 32-bit buffer offsets (masks)
+  a->lw = lw;
+  a->lrw = fb_ilog2_exact(a->R * s.W);
+  a->lhw = fb_ilog2_exact(g.RH * s.W);   // -1 when TS == 1 with halo rows: unused there
+  if (a->lrw < 0 || (a->TS > 1 && a->lhw < 0)) return false;
+  if (a->lhw < 0) a->lhw = 0;
+  // instantiated for the shapes Glow produces
+  return (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) || (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) ||
+         (g.MT32 == 2 && g.NTD == 2 && g.K3M == 28) || (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) ||
+         (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4);
+}
+
+template <int MT32, int NTD, int K3M>
+static int fb_launch_t(const FBArgs& a, const FBGeom& g, int grid, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusedb_step_bwd_kernel<MT32, NTD, K3M>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+      return NFK_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((fusedb_step_bwd_kernel<MT32, NTD, K3M>), dim3(grid), dim3(256), g.total, st, a);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int fusedb_grid(const nfk_step2d& s) {
+  FBArgs a{};
+  if (!fb_pick(s, &a)) return 0;
+  return a.TS == 1 ? s.B * (s.H / a.R) : (s.B + a.TS - 1) / a.TS;
+}
+
+int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
+  FBArgs a{};
+  if (!c.masks || !fb_pick(c.s, &a)) return NFK_ERR_ARG;
+  a.c = c;
+  const nfk_step2d& s = c.s;
+  const FBGeom g = fb_geom(s, a.R, a.TS, a.halo);
+  const int grid = a.TS == 1 ? s.B * (s.H / a.R) : (s.B + a.TS - 1) / a.TS;
+  const double M = (double)s.B * s.H * s.W;
+  const int cls = NFK_PROF_FUSED_BWD + (M >= 8192 ? 0 : (M >= 2048 ? 1 : 2));
+  prof_scope_begin(cls, 2.0 * M * (512.0 * 9 * s.Cout + 512.0 * 512 + 9.0 * 512 * (s.C / 2)),
+                   M * (4.0 * s.Cout + 4.0 * (s.C / 2) + 2 * 512 * 2.0 + 2 * 64.0) + 2.0 * 512 * (9.0 * s.Cout + 512 + 9.0 * (s.C / 2)), st);
+  int rc = NFK_ERR_ARG;
+  if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<3, 1, 8>(a, g, grid, st);
+  else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) rc = fb_launch_t<3, 1, 4>(a, g, grid, st);
+  else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<2, 1, 8>(a, g, grid, st);
+  else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) rc = fb_launch_t<2, 1, 16>(a, g, grid, st);
+  else if (g.MT32 == 2 && g.NTD == 2 && g.K3M == 28) rc = fb_launch_t<2, 2, 28>(a, g, grid, st);
+  prof_scope_end(cls, st);
+  return rc;
+}
+
+}  // namespace nfk

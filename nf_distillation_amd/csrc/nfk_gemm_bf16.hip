@@ -900,6 +900,127 @@ static int launch_dual(const ConvGemmArgs& d, int SD, const WgradArgs& w, int SW
   return NFK_OK;
 }
 
+// Per-channel sums behind the two ActNorm layers' gradients (block.2: g_a2 with h2, block.0: g_a1 with h1), over this
+// workgroup's share of the pixels:  col[part][0][c] = sum_m ga[m][c] h[m][c] / e^logs[c],  col[part][1][c] = sum_m ga[m][c]
+// (the [rows][2][N] partial-row layout of the dgrad epilogues, reduced by the step tail).  A thread owns 8 channels
+// (one 16-byte piece of a row); the 4 waves take every 4th pixel and are summed through LDS in fixed order.
+constexpr int AN_PARTS_MAX = 64;
+int actnorm_sum_parts(int M) {
+  const int p = M / 64;   // at least 64 pixels per workgroup
+  return p < 1 ? 1 : (p > AN_PARTS_MAX ? AN_PARTS_MAX : p);
+}
+__device__ __forceinline__ void actnorm_sum_body(const ActnormSumArgs& a, const int part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  float* red = reinterpret_cast<float*>(smem_b);   // [4 waves][2 layers][2 sums][512]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m_begin = (int)((long)a.M * part / a.nparts), m_end = (int)((long)a.M * (part + 1) / a.nparts);
+  const unsigned bytes = (unsigned)((long)a.M * a.hid * 2);
+  const __amdgpu_buffer_rsrc_t rG2 = rsrc_of(a.ga2, bytes), rH2 = rsrc_of(a.h2, bytes), rG1 = rsrc_of(a.ga1, bytes),
+                               rH1 = rsrc_of(a.h1, bytes);
+  float s2l[8], s2b[8], s1l[8], s1b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s2l[e] = 0.f; s2b[e] = 0.f; s1l[e] = 0.f; s1b[e] = 0.f; }
+  auto acc8 = [](const u32x4b g, const u32x4b h, float (&sl)[8], float (&sb)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = __builtin_bit_cast(float, g[e] << 16), g1 = __builtin_bit_cast(float, g[e] & 0xFFFF0000u);
+      const float h0 = __builtin_bit_cast(float, h[e] << 16), h1 = __builtin_bit_cast(float, h[e] & 0xFFFF0000u);
+      sl[2 * e] += g0 * h0; sl[2 * e + 1] += g1 * h1;
+      sb[2 * e] += g0; sb[2 * e + 1] += g1;
+    }
+  };
+  // 4 pixels per wave in flight (16 loads): a chain of dependent round trips otherwise
+  for (int m = m_begin + wid; m < m_end; m += 16) {
+    u32x4b g2[4], h2[4], g1[4], h1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mm = m + 4 * u;
+      const unsigned off = mm < m_end ? (unsigned)((mm * a.hid + lane * 8) * 2) : OOB;
+      g2[u] = ld16(rG2, off); h2[u] = ld16(rH2, off); g1[u] = ld16(rG1, off); h1[u] = ld16(rH1, off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc8(g2[u], h2[u], s2l, s2b); acc8(g1[u], h1[u], s1l, s1b); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float* r = red + wid * 2048 + lane * 8 + e;
+    r[0] = s2l[e]; r[512] = s2b[e]; r[1024] = s1l[e]; r[1536] = s1b[e];
+  }
+  __syncthreads();
+  for (int t = tid; t < 2048; t += 256) {
+    const int layer = t >> 10, which = (t >> 9) & 1, c = t & 511;
+    float v = (red[t] + red[2048 + t]) + (red[4096 + t] + red[6144 + t]);
+    if (which == 0) v /= (layer == 0 ? a.es2 : a.es1)[c];
+    (layer == 0 ? a.col2 : a.col1)[((long)part * 2 + which) * a.hid + c] = v;
+  }
+}
+
+// The three weight-gradient GEMMs of one FlowStep in ONE launch (the fused backward, nfk_fusedb.hip, has produced all
+// three output gradients by then): conv2's 512x512 tiles first (the longest workgroups), then conv1's, then conv3's,
+// then the ActNorm sums (bandwidth work beside latency-bound GEMMs).
+// V3: body of conv3's narrow weight gradient -- 0 = the halo-tile kernel, 1..3 = the generic body with V3 row tiles.
+template <int V3>
+__global__ void __launch_bounds__(256) triple_wgrad_bf16_kernel(WgradArgs w2, int nb2, int S2, WgradArgs w1, int nb1, int S1,
+                                                                WgradArgs w3, int nb3, int S3, int n3, ActnormSumArgs an) {
+  int b = blockIdx.x;
+  if (b < nb2 * S2) { wgrad_bf16_body<4, 4, 2, 2>(w2, b % nb2, S2, b / nb2); return; }
+  b -= nb2 * S2;
+  if (b < nb1 * S1) { wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1); return; }
+  b -= nb1 * S1;
+  if (b < n3) {
+    if (V3 == 0) wgrad_halo_body(w3, b, S3);
+    else wgrad_bf16_body<(V3 > 0 ? V3 : 1), 2, 1, 4>(w3, b % nb3, S3, b / nb3);
+    return;
+  }
+  actnorm_sum_body(an, b - n3);
+}
+
+template <int V3>
+static int launch_triple(const WgradArgs& w3, int S3, const WgradArgs& w2, int S2, const WgradArgs& w1, int S1,
+                         const ActnormSumArgs& an, hipStream_t st) {
+  constexpr size_t ldsWide = 2 * WPX * (wg_stride(128) + wg_stride(128));
+  const size_t lds3 = V3 == 0 ? wh_lds_bytes(w3.W) : 2 * WPX * (wg_stride(16 * (V3 > 0 ? V3 : 1)) + wg_stride(128));
+  const size_t lds = ldsWide > lds3 ? ldsWide : lds3;   // (the ActNorm sums need 32 KiB)
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(triple_wgrad_bf16_kernel<V3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  if (lds > 80 * 1024 || an.hid != 512 || an.nparts < 1) return NFK_ERR_ARG;
+  const int nb2 = ceil_div(w2.NI, 128) * ceil_div(w2.J, 128), nb1 = ceil_div(w1.NI, 128) * ceil_div(w1.J, 128);
+  const int nb3 = V3 == 0 ? (w3.Cq / 128) * S3 : ceil_div(w3.NI, 16 * (V3 > 0 ? V3 : 1)) * ceil_div(w3.J, 128);
+  const int n3 = V3 == 0 ? nb3 : nb3 * S3;
+  const int cls = NFK_PROF_TRIPLE_WGRAD + (w2.M >= 8192 ? 0 : (w2.M >= 2048 ? 1 : 2));
+  prof_scope_begin(cls, 2.0 * w2.M * ((double)w2.NI * w2.J + (double)w1.NI * w1.J + (double)w3.NI * w3.J),
+                   w2.M * (2.0 * w2.NI + 2.0 * w2.Cq + 2.0 * w1.NI + 4.0 * w1.Cq + 4.0 * w3.NI + 2.0 * w3.Cq) +
+                       4.0 * (S2 * (double)w2.NI * w2.J + S1 * (double)w1.NI * w1.J + S3 * (double)w3.NI * w3.J), st);
+  hipLaunchKernelGGL((triple_wgrad_bf16_kernel<V3>), dim3(nb2 * S2 + nb1 * S1 + n3 + an.nparts), dim3(256), lds, st, w2, nb2,
+                     S2, w1, nb1, S1, w3, nb3, S3, n3, an);
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
+int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an,
+                      hipStream_t st) {
+  for (WgradArgs* w : {&w3, &w2, &w1}) {
+    w->M = w->B * w->H * w->W;
+    w->J = w->taps * w->Cq;
+    if (w->M <= 0 || w->NI <= 0 || w->J <= 0) return NFK_ERR_ARG;
+    if ((long)w->M * w->ldp * 4 >= 0x7fffffffL || (long)w->M * w->ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
+  }
+  if (w2.NI <= 96 || w1.NI <= 96 || w3.NI > 48 || !w2.pbf16 || !w2.qbf16 || !w1.pbf16) return NFK_ERR_ARG;
+  if (!w3.pbf16 && w3.qbf16 && wgrad_halo_usable(w3.M, w3.NI, w3.Cq, w3.taps, w3.W) && S3 == wgrad_halo_splits(w3.M))
+    return launch_triple<0>(w3, S3, w2, S2, w1, S1, an, st);
+  switch (ceil_div(w3.NI, 16)) {
+    case 1: return launch_triple<1>(w3, S3, w2, S2, w1, S1, an, st);
+    case 2: return launch_triple<2>(w3, S3, w2, S2, w1, S1, an, st);
+    case 3: return launch_triple<3>(w3, S3, w2, S2, w1, S1, an, st);
+  }
+  return NFK_ERR_ARG;
+}
+
 template <int TN, int TM, int WN, int WM>
 static int launch_wgrad_bf16(const WgradArgs& a, int S, hipStream_t st, int cls) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;

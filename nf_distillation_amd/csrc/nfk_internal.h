@@ -115,12 +115,36 @@ struct FusedCall {
   void* h1save;          // [M][hid] bf16 or null
   void* h2save;          // [M][hid] bf16 or null
   float* hsave;          // [M][Cout] or null
+  unsigned char* masksave;  // [2][M][hid/8] ReLU masks of h1 / h2 (bit c%8 of byte c/8), with h1save / h2save, or null
   float* zout;           // [M][C]
   float* ldpart;         // [B][tiles per sample] partial log-det of this step
   float* ws;             // fused2_ws_floats(s) floats: partial conv3 slabs of a hidden-split step (else unused)
   unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
   int dbg;                     // diagnostic bisect bits (0 in production)
 };
+// one fused FlowStep backward call (nfk_fusedb.hip): the dgrad chain g_a3 -> g_a2 -> g_a1 -> g_z1 contribution
+struct FusedBwdCall {
+  nfk_step2d s;
+  const float* ga3;      // [M][Cout] gradient wrt conv3's raw output (coupling backward)
+  const unsigned char* masks;  // [2][M][hid/8] ReLU masks of h1 / h2 left by the fused forward (FusedCall.masksave)
+  void* ga2;             // [M][hid] bf16 out: operand of conv2's weight gradient
+  void* ga1;             // [M][hid] bf16 out: operand of conv1's weight gradient
+  float* d1;             // [M][C/2] out: dgrad1 (added to g_z1 by the channel-mix backward)
+  unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
+};
+// per-channel sums behind the two ActNorm layers' gradients, over a range of pixels (a 4th body of the triple launch):
+//   col[part][0][c] = sum_m ga[m][c] h[m][c] / es[c]   (dlogs),   col[part][1][c] = sum_m ga[m][c]   (dbias)
+struct ActnormSumArgs {
+  const void *ga2, *h2, *ga1, *h1;   // [M][hid] bf16
+  const float *es2, *es1;            // [hid]
+  float *col2, *col1;                // [nparts][2][hid]
+  int M, hid, nparts;
+};
+int actnorm_sum_parts(int M);
+int fusedb_grid(const nfk_step2d& s);    // workgroups (= partial rows in col1 / col2) of the fused backward, 0 = not supported
+int fusedb_launch(const FusedBwdCall& c, hipStream_t st);
+// the three weight-gradient GEMMs of a step (block.4, .2, .0) in ONE launch; NFK_ERR_ARG: shapes not instantiated
+int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an, hipStream_t st);
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 int fused2_launch(const FusedCall& c, hipStream_t st);
 size_t fused2_ws_floats(const nfk_step2d& s);

@@ -70,6 +70,7 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
   __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
+  __bf16* wg = (d.wd && d.gfrag) ? reinterpret_cast<__bf16*>(d.wg) : nullptr;
   for (int t = bx * nthr + tid; t < n8_f + n8_d + n8_g; t += nbx * nthr) {
     float v[8];
     __bf16* dst;
@@ -107,6 +108,13 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
         if (++co == d.Cout) { co = 0; ++tap; }
       }
       dst = wd + (long)u * 8;
+      if (wg) {   // the same 8 elements once more, at their place in the fragment-ordered copy
+        const rp_u32x4 pkg = {rp_pack2(v[0], v[1]), rp_pack2(v[2], v[3]), rp_pack2(v[4], v[5]), rp_pack2(v[6], v[7])};
+        long ug;
+        if (d.gfrag == 1) ug = ((long)((ci >> 5) * (Kpd / 16) + (k0 >> 4)) << 6) + (ci & 31) + 32 * ((k0 >> 3) & 1);
+        else ug = ((long)((ci >> 4) * (Kpd / 32) + (k0 >> 5)) << 6) + (ci & 15) + 16 * ((k0 >> 3) & 3);
+        *reinterpret_cast<rp_u32x4*>(wg + ug * 8) = pkg;
+      }
     }
     const rp_u32x4 pk = {rp_pack2(v[0], v[1]), rp_pack2(v[2], v[3]), rp_pack2(v[4], v[5]), rp_pack2(v[6], v[7])};
     *reinterpret_cast<rp_u32x4*>(dst) = pk;
@@ -125,6 +133,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
   __bf16* wt = reinterpret_cast<__bf16*>(d.wt);
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
+  __bf16* wg = (d.wd && d.gfrag) ? reinterpret_cast<__bf16*>(d.wg) : nullptr;
   const unsigned mCin = 0xFFFFFFFFu / (unsigned)Cin + 1u, mCout = 0xFFFFFFFFu / (unsigned)Cout + 1u;   // n / C for n < 2^16
   // the trip count is the same for every worker of the weight (barriers are workgroup-wide, and a workgroup may hold
   // two workers): a worker without a tile in the last trip runs it with an empty tile
@@ -184,6 +193,12 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
         }
         const rp_u32x4 pk = {rp_pack2(v[0], v[1]), rp_pack2(v[2], v[3]), rp_pack2(v[4], v[5]), rp_pack2(v[6], v[7])};
         *reinterpret_cast<rp_u32x4*>(wd + (long)ci * Kpd + k0) = pk;
+        if (wg) {
+          long ug;
+          if (d.gfrag == 1) ug = ((long)((ci >> 5) * (Kpd / 16) + (k0 >> 4)) << 6) + (ci & 31) + 32 * ((k0 >> 3) & 1);
+          else ug = ((long)((ci >> 4) * (Kpd / 32) + (k0 >> 5)) << 6) + (ci & 15) + 16 * ((k0 >> 3) & 3);
+          *reinterpret_cast<rp_u32x4*>(wg + ug * 8) = pk;
+        }
       }
     }
   }

@@ -152,6 +152,13 @@ class FlowEngine:
                                         ("wf3", (r.Cout + 15) // 16 * 16 * pk(9 * hid))):
                             off[name] = o
                             o += (n + 7) & ~7
+                        if any(p.requires_grad for p in layer.parameters()):
+                            # ... and of the dgrad weights, for the fused step backward (nfk_fusedb.hip); rows behind
+                            # C/2 of wg1 stay zero (the buffer is zero-initialised and the repack never writes them)
+                            for name, n in (("wg3", hid * pk(9 * r.Cout)), ("wg2", hid * pk(hid)),
+                                            ("wg1", (Ch + 15) // 16 * 16 * pk(9 * hid))):
+                                off[name] = o
+                                o += (n + 7) & ~7
                     step_pack = o
                 plan.append((r, off))
             elif isinstance(layer, M.Split2d):
@@ -222,13 +229,14 @@ class FlowEngine:
                         setattr(cs, nm, pb + 4 * off[nm])
                     for nm in ("wt1", "wt2", "wt3", "wd1", "wd2", "wd3"):
                         setattr(cs, nm, sb + esz * off[nm])
-                    for nm in ("wf1", "wf2", "wf3"):
+                    for nm in ("wf1", "wf2", "wf3", "wg1", "wg2", "wg3"):
                         setattr(cs, nm, sb + esz * off[nm] if nm in off else None)
                     r.cs = cs
                     Ch = r.C // 2
-                    for w, co, ci, taps, a, b, f, fk in ((blk[0].conv.weight, r.hid, Ch, 9, "wt1", "wd1", "wf1", 1),
-                                                         (blk[2].conv.weight, r.hid, r.hid, 1, "wt2", "wd2", "wf2", 1),
-                                                         (blk[4].conv.weight, r.Cout, r.hid, 9, "wt3", "wd3", "wf3", 2)):
+                    for w, co, ci, taps, a, b, f, fk, gname, gk in (
+                            (blk[0].conv.weight, r.hid, Ch, 9, "wt1", "wd1", "wf1", 1, "wg1", 2),
+                            (blk[2].conv.weight, r.hid, r.hid, 1, "wt2", "wd2", "wf2", 1, "wg2", 1),
+                            (blk[4].conv.weight, r.Cout, r.hid, 9, "wt3", "wd3", "wf3", 2, "wg3", 1)):
                         _check_param(w, "conv.weight")
                         if tuple(w.shape) != (co, ci, 3 if taps == 9 else 1, 3 if taps == 9 else 1):
                             raise ValueError(f"layer {r.idx}: unexpected conv weight shape {tuple(w.shape)}")
@@ -237,6 +245,8 @@ class FlowEngine:
                         rd.Cout, rd.Cin, rd.taps = co, ci, taps
                         if f in off:
                             rd.wf, rd.frag = sb + esz * off[f], fk
+                        if gname in off:
+                            rd.wg, rd.gfrag = sb + esz * off[gname], gk
                         step_repack.append(rd)
                 else:
                     from .tabular import TabStep
@@ -540,15 +550,19 @@ class _EncodeFn(torch.autograd.Function):
                            "tiles": tiles}
                 M_ = B * r.H * r.W
                 out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
-                zb = h1 = h2 = hs = None
+                zb = h1 = h2 = hs = masks = None
                 if need:
-                    arena = torch.empty(_a4(M_ * r.C) + 2 * _a4(M_ * r.hid) + _a4(M_ * r.Cout), device=dev,
+                    # ReLU masks of h1 / h2 (one bit per element) for the fused step backward, behind the other saves
+                    nmask = _a4((lib.nfk_step2d_mask_bytes(C.byref(r.cs)) + 3) // 4) if r.cs.wg1 else 0
+                    arena = torch.empty(_a4(M_ * r.C) + 2 * _a4(M_ * r.hid) + _a4(M_ * r.Cout) + nmask, device=dev,
                                         dtype=torch.float32)
                     o1 = _a4(M_ * r.C)
                     o2 = o1 + _a4(M_ * r.hid)
                     o3 = o2 + _a4(M_ * r.hid)
-                    zb, h1, h2, hs = arena[:o1], arena[o1:o2], arena[o2:o3], arena[o3:]
-                    saved.append((cur, zb, h1, h2, hs, arena))
+                    o4 = o3 + _a4(M_ * r.Cout)
+                    zb, h1, h2, hs = arena[:o1], arena[o1:o2], arena[o2:o3], arena[o3:o4]
+                    masks = arena[o4:] if nmask else None
+                    saved.append((cur, zb, h1, h2, hs, arena, masks))
                 else:
                     saved.append(None)
                 # hidden split of this launch: the engine's policy for a training / an inference forward
@@ -565,7 +579,7 @@ class _EncodeFn(torch.autograd.Function):
                         (ws,) = scratch.get(nws)
                 part = run["buf"].data_ptr() + 4 * run["k"] * B * tiles
                 check(lib.nfk_step2d_fwd_fused(C.byref(r.cs), ptr(cur), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs), ptr(out),
-                                               part, ptr(ws), s), "nfk_step2d_fwd_fused")
+                                               part, ptr(ws), ptr(masks), s), "nfk_step2d_fwd_fused")
                 run["k"] += 1
                 if run["k"] == run["n"]:
                     ld_out = torch.empty_like(ld)
@@ -588,7 +602,7 @@ class _EncodeFn(torch.autograd.Function):
                     o3 = o2 + _a4(M_ * r.hid)
                     zb, h1, h2, hs = arena[:o1], arena[o1:o2], arena[o2:o3], arena[o3:]
                     (ws,) = scratch.get(nws)
-                    saved.append((cur, zb, h1, h2, hs, arena))
+                    saved.append((cur, zb, h1, h2, hs, arena, None))
                 else:
                     zb, h1, h2, ws = scratch.get(M_ * r.C, M_ * r.hid, M_ * r.hid, nws)
                     hs = None
@@ -714,9 +728,10 @@ class _EncodeFn(torch.autograd.Function):
             if g is None and ext is None:
                 continue  # nothing flows into this layer's output
             if r.kind == "step" and ws_pair is not None:
-                x_in, zb, h1, h2, hs, _ = sv
+                x_in, zb, h1, h2, hs, _, masks = sv
                 blk = r.mod.block
                 gs = Step2dGrads()
+                gs.relu_masks = ptr(masks)
                 gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
                 gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
                 gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
@@ -747,9 +762,10 @@ class _EncodeFn(torch.autograd.Function):
                 if eng.grad_hook is not None:
                     eng.grad_hook(r.idx)
             elif r.kind == "step":
-                x_in, zb, h1, h2, hs, _ = sv
+                x_in, zb, h1, h2, hs, _, masks = sv
                 blk = r.mod.block
                 gs = Step2dGrads()
+                gs.relu_masks = ptr(masks)
                 gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
                 gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
                 gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)

@@ -203,7 +203,7 @@ def _grads_with(mode, halo, g, cfg, sd, x, noise, chain=False):
         torch.cuda.synchronize()
         return {k: p.grad.cpu() for k, p in model.named_parameters()}
     finally:
-        lib.nfk_set_bwd_mode(2)
+        lib.nfk_set_bwd_mode(3)
         lib.nfk_set_tuning(3001)
         lib.nfk_set_tuning(3011)
 

@@ -4,6 +4,8 @@ The layouts replace what the reference hands to cuDNN as `conv.weight` (models/l
   wt [Cout][Kp]      forward implicit GEMM, k = tap * Cin + ci, zero padded to a multiple of 64
   wd [Cin][Kpd]      dgrad: k = tap * Cout + co with the taps flipped
   wf                 wt once more in MFMA A-fragment order (1: 32x32x16, 2: 16x16x32; include/nfk.h)
+  wg                 wd once more in MFMA A-fragment order (the fused step backward's operands; rows behind Cin of a
+                     16-row layout are left untouched: the caller keeps the buffer zeroed)
 bf16 conversion is round-to-nearest-even, so every element must agree bit for bit."""
 import pytest
 import torch
@@ -36,6 +38,20 @@ def _expected(w, frag, Kp, Kpd):
     return wt, wd, wf
 
 
+def _frag_order(mat, kind):
+    """[rows][Kp] -> fragment order of `kind` (rows padded with zeros to the fragment height)."""
+    rows, kk = (32, 16) if kind == 1 else (16, 32)
+    R = (mat.shape[0] + rows - 1) // rows * rows
+    full = torch.zeros(R, mat.shape[1], dtype=mat.dtype)
+    full[:mat.shape[0]] = mat
+    return full.view(R // rows, rows, mat.shape[1] // kk, kk // 8, 8).permute(0, 2, 3, 1, 4).reshape(-1).contiguous()
+
+
+def _gkind(Cout, Cin, taps):
+    """dgrad fragment layout requested for a case: 32-row fragments where Cin allows, else 16-row ones (K % 32 == 0)."""
+    return 1 if Cin % 32 == 0 else 2
+
+
 @pytest.mark.parametrize("entry", ["nfk_repack_batch_bf16", "nfk_prep_repack"])
 def test_repack_bf16_layouts(entry):
     """`nfk_prep_repack` runs the same repack bodies inside the launch that also prepares the steps (two 256-thread
@@ -57,8 +73,11 @@ def test_repack_bf16_layouts(entry):
         d.w, d.wt, d.wd = wdev.data_ptr(), wt.data_ptr(), wd.data_ptr()
         d.Cout, d.Cin, d.taps, d.frag = Cout, Cin, taps, frag
         d.wf = wf.data_ptr() if frag else None
+        gk = _gkind(Cout, Cin, taps)
+        wg = torch.zeros(_frag_order(ewd, gk).numel(), dtype=torch.bfloat16, device=dev)
+        d.wg, d.gfrag = wg.data_ptr(), gk
         descs.append(d)
-        keep.append((wdev, wt, wd, wf))
+        keep.append((wdev, wt, wd, wf, wg))
         exp.append((ewt, ewd, ewf))
     dd = capi.struct_array_to_device(descs, dev)
     if entry == "nfk_repack_batch_bf16":
@@ -66,7 +85,9 @@ def test_repack_bf16_layouts(entry):
     else:
         capi.check(lib.nfk_prep_repack(None, 0, 0, None, 0, dd.data_ptr(), len(descs), None), entry)
     torch.cuda.synchronize()
-    for case, (_, wt, wd, wf), (ewt, ewd, ewf) in zip(CASES, keep, exp):
+    for case, (_, wt, wd, wf, wg), (ewt, ewd, ewf) in zip(CASES, keep, exp):
+        ewg = _frag_order(ewd, _gkind(*case[:3]))
+        assert torch.equal(wg.cpu().view(torch.int16), ewg.view(torch.int16)), ("wg", case)
         assert torch.equal(wt.cpu().view(torch.int16), ewt.reshape(-1).view(torch.int16)), ("wt", case)
         assert torch.equal(wd.cpu().view(torch.int16), ewd.reshape(-1).view(torch.int16)), ("wd", case)
         if wf is not None:

@@ -138,7 +138,7 @@ def test_aux_stream_deferred_join_is_bit_identical():
             step.enable_concurrency(False)
             res.append({k: v.cpu() for k, v in student.state_dict().items()})
     finally:
-        capi.lib().nfk_set_bwd_mode(2)
+        capi.lib().nfk_set_bwd_mode(3)   # the library's default
         capi.lib().nfk_set_aux_stream(None)
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
