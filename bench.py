@@ -98,6 +98,9 @@ class Leg:
         from nf_distillation_amd.training import DistillationStep
         self.args, self.dtype, self.data, self.world = args, dtype, data, world
         self.student, self.teacher = make_models(device, dtype)
+        if args.fused_runs is not None:
+            self.teacher.flow.engine().fused_runs = args.fused_runs in ("both", "teacher")
+            self.student.flow.engine().fused_runs = args.fused_runs in ("both", "student")
         self.step = DistillationStep(self.student, self.teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
         if not args.no_overlap:
             self.step.enable_concurrency()  # teacher fwd || student fwd, wgrad || dgrad on side streams
@@ -257,6 +260,9 @@ def main():
                          "instead of the default software pipeline: teacher forward for batch t+1 beside the "
                          "student's step on batch t (nf_distillation_amd/pipeline.py; same values, every call still "
                          "does one teacher forward + one student forward/backward + one optimiser step)")
+    ap.add_argument("--fused-runs", choices=("both", "teacher", "student", "off"), default=None,
+                    help="experiment knob: which model walks a whole level's FlowSteps in ONE launch (levels 2 / 3; "
+                         "default: the engines' default)")
     ap.add_argument("--tuning", type=int, default=None, help="experiment knob: nfk_set_tuning(v)")
     ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_set_bwd_mode(v) (0: dgrad and wgrad as "
                                                                  "separate launches, 2: one launch per conv, default)")

@@ -243,26 +243,50 @@ size_t nfk_step2d_mask_bytes(const nfk_step2d *s);   /* size of nfk_step2d_fwd_f
 /* diagnostic: device buffer [workgroups][16] of shader-clock stamps per phase of the fused backward (NULL = off) */
 void nfk_fused_bwd_set_stamps(void *buf);
 void *nfk_get_aux_stream(void);
-/* Fused forward of one FlowStep in ONE launch (bf16 mode, 64-pixel row tiles; see csrc/nfk_fused.hip).
+/* Fused forward of one FlowStep in ONE launch (bf16 mode, 64-pixel row tiles; see csrc/nfk_fused2.hip).
  * nfk_step2d_fused_tiles: 0 if this step's geometry is not supported (use nfk_step2d_fwd), else the number of
  * log-det partial slots per sample.  zsave/h1save/h2save/hsave as in nfk_step2d_fwd (NULL when no backward
  * follows; h1save/h2save are bf16 [M][hidden]).  The per-sample log-det is NOT updated here: the step writes
- * ldpart[B][tiles] and nfk_ld_finish adds the partials of a run of steps to ld_in in fixed order. */
+ * ldpart[B][tiles] and nfk_ld_finish adds the partials of a run of steps to ld_in in fixed order.
+ * masksave (optional, with h1save / h2save): [2][M][hidden/8] bytes, bit c%8 of byte [k][m][c/8] = (h_{k+1}[m][c] > 0), the
+ * ReLU masks of the two hidden activations -- all the fused step backward needs of them (`relu_masks` of nfk_step2d_grads).
+ * split_ways: 4, 2 or 0.  "Hidden split": a grid that would fill only 16-64 CUs gives every pixel tile to that many
+ * workgroups, each with its share of conv2 / conv3, partial sums in ws (nfk_step2d_fused_ws_floats(s) floats; 0 when the
+ * geometry never splits), finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows.
+ * split_ways == 0 or ws == NULL: no split (the step runs on its 16-64 workgroups). */
 int nfk_step2d_fused_tiles(const nfk_step2d *s);
-/* diagnostic: device buffer [workgroups][8] of shader-clock stamps per phase of the fused kernel (NULL = off) */
-void nfk_fused_set_stamps(void *buf);
-void nfk_fused_set_debug(int bits); /* diagnostic bisect of the fused kernel (results become wrong); 0 = off */
-int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zsave, void *h1save, void *h2save,
-                         float *hsave, float *zout, float *ldpart, float *ws, void *masksave, void *stream);
-/* masksave (optional, with h1save / h2save): [2][M][hidden/8] bytes, bit c%8 of byte [k][m][c/8] = (h_{k+1}[m][c] > 0), the
- * ReLU masks of the two hidden activations -- all the fused step backward needs of them (`masks` of nfk_step2d_bwd*). */
-/* ws: nfk_step2d_fused_ws_floats(s) floats (0 for most steps).  Non-zero means the step runs "hidden split": grids that
- * would fill only 16-64 CUs give every pixel tile to 4 workgroups, each with a quarter of conv2/conv3, partial sums in
- * ws, finished by the coupling kernel -- zsave must then be non-NULL even when no backward follows.  Passing ws == NULL
- * declines the split (the step then runs on its 16-64 workgroups). */
 size_t nfk_step2d_fused_ws_floats(const nfk_step2d *s);
-/* hidden split of the following fused launches: 4 (default), 2, or 0 = none (host-side launch parameter) */
-void nfk_fused_set_split(int ways);
+int nfk_step2d_fwd_fused(const nfk_step2d *s, const float *x, int ldx, float *zsave, void *h1save, void *h2save,
+                         float *hsave, float *zout, float *ldpart, float *ws, void *masksave, int split_ways,
+                         void *stream);
+/* diagnostic: device buffer [workgroups][16] of shader-clock stamps per phase of the fused kernel (NULL = off) */
+void nfk_fused_set_stamps(void *buf);
+/* A RUN of FlowSteps of one level in ONE launch (models/kd_flows.py:42-53 walks them one by one): for geometries whose
+ * pixel tiles are whole images (H*W <= 64: CIFAR levels 2 and 3) a step's output tile is the next step's input tile, so
+ * the activations stay in LDS from step to step and only what somebody reads goes to HBM.  Bit-identical to calling
+ * nfk_step2d_fwd_fused (split_ways 0) once per step.
+ *   steps     DEVICE array [nsteps] of descriptors with identical B, H, W, C, hidden, Cout, additive (nsteps <= 64)
+ *   keep      bit k set: the output of step k is written to zout + slot * zout_stride (floats), slot = number of set
+ *             bits below k; the last step's bit must be set.  A training forward sets all bits (a step's output is what
+ *             the next step's backward reads as its input).
+ *   zsave, h1save, h2save, hsave, masksave: per-step buffers as in nfk_step2d_fwd_fused, step k at base + k * stride
+ *             (strides in floats / bf16 elements / floats / bytes); all NULL when no backward follows
+ *   ldpart    [nsteps][B][tiles] log-det partials, finished by nfk_ld_finish as for single steps
+ * nfk_run2d_fused_ok: 1 if this step geometry can run as such a run.  `first`: HOST copy of steps[0]. */
+typedef struct nfk_fused_run {
+  const nfk_step2d *steps;
+  int32_t nsteps, ldx;
+  const float *x;
+  uint64_t keep;
+  float *zout; int64_t zout_stride;
+  float *zsave; int64_t zsave_stride;
+  void *h1save, *h2save; int64_t h_stride;
+  float *hsave; int64_t hsave_stride;
+  void *masksave; int64_t mask_stride;
+  float *ldpart;
+} nfk_fused_run;
+int nfk_run2d_fused_ok(const nfk_step2d *s);
+int nfk_run2d_fwd_fused(const nfk_fused_run *run, const nfk_step2d *first, void *stream);
 int nfk_ld_finish(const float *ld_in, const float *ldpart, int nsteps, int B, int tiles, float *ld_out, void *stream);
 /* Split2d.forward / reverse / backward */
 int nfk_split2d_fwd(const nfk_split2d *s, const float *x, const float *ld_in, float *z1out, float *hsave,

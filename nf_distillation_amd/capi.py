@@ -56,6 +56,14 @@ class Step2dGrads(C.Structure):
                 ("relu_masks", c_fp)]
 
 
+class FusedRun(C.Structure):
+    """nfk_fused_run (include/nfk.h): a run of FlowSteps of one level walked by ONE launch."""
+    _fields_ = [("steps", c_fp), ("nsteps", C.c_int32), ("ldx", C.c_int32), ("x", c_fp), ("keep", C.c_uint64),
+                ("zout", c_fp), ("zout_stride", C.c_int64), ("zsave", c_fp), ("zsave_stride", C.c_int64),
+                ("h1save", c_fp), ("h2save", c_fp), ("h_stride", C.c_int64), ("hsave", c_fp), ("hsave_stride", C.c_int64),
+                ("masksave", c_fp), ("mask_stride", C.c_int64), ("ldpart", c_fp)]
+
+
 class Step2dNext(C.Structure):
     _fields_ = [("s", C.POINTER(Step2d)), ("z", c_fp), ("hsave", c_fp), ("g_ext", c_fp), ("ws", c_fp), ("ga", c_fp)]
 
@@ -144,10 +152,10 @@ _PROTOS = {
     "nfk_step2d_mask_bytes": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_fused_tiles": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_set_stamps": (None, [vp]),
-    "nfk_fused_set_debug": (None, [i32]),
-    "nfk_fused_set_split": (None, [i32]),
-    "nfk_step2d_fwd_fused": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_step2d_fwd_fused": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "nfk_step2d_fused_ws_floats": (u64, [C.POINTER(Step2d)]),
+    "nfk_run2d_fused_ok": (i32, [C.POINTER(Step2d)]),
+    "nfk_run2d_fwd_fused": (i32, [C.POINTER(FusedRun), C.POINTER(Step2d), vp]),
     "nfk_ld_finish": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nfk_split2d_fwd": (i32, [C.POINTER(Split2d), vp, vp, vp, vp, vp, vp, vp]),
     "nfk_split2d_inv": (i32, [C.POINTER(Split2d), vp, vp, f32, vp, vp, vp]),

@@ -107,7 +107,7 @@ struct PriorBwdArgs {
   int HW, C; float bpd_scale;
 };
 
-// one fused FlowStep forward call (nfk_fused.hip / nfk_fused2.hip)
+// one fused FlowStep forward call (nfk_fused2.hip)
 struct FusedCall {
   nfk_step2d s;
   const float* x; int ldx;
@@ -120,7 +120,7 @@ struct FusedCall {
   float* ldpart;         // [B][tiles per sample] partial log-det of this step
   float* ws;             // fused2_ws_floats(s) floats: partial conv3 slabs of a hidden-split step (else unused)
   unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
-  int dbg;                     // diagnostic bisect bits (0 in production)
+  int split_ways;              // hidden split requested by the caller: 4, 2 or 0 (none); see nfk_step2d_fwd_fused
 };
 // one fused FlowStep backward call (nfk_fusedb.hip): the dgrad chain g_a3 -> g_a2 -> g_a1 -> g_z1 contribution
 struct FusedBwdCall {
@@ -148,7 +148,6 @@ int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, 
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 int fused2_launch(const FusedCall& c, hipStream_t st);
 size_t fused2_ws_floats(const nfk_step2d& s);
-void fused2_set_split(int on);
 
 void set_tuning(int v);
 void prof_begin();

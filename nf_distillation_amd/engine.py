@@ -59,6 +59,9 @@ class FlowEngine:
         self.fused_split_inference = 4   # ways: 4, 2, 0 (none) or "frugal" (see _EncodeFn.forward)
         self.fused_split_training = 4    # the same for a forward that keeps what the backward needs
         self.chain_backward = True       # nfk_step2d_bwd_chain (False: one independent nfk_step2d_bwd call per step)
+        # all FlowSteps of a level in ONE launch where the pixel tiles are whole images (nfk_run2d_fwd_fused; bit-identical
+        # to the per-step launches without hidden split).  "inference": only for passes that keep nothing (a frozen teacher)
+        self.fused_runs = True
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -266,7 +269,26 @@ class FlowEngine:
             r.prep_i = len(prep_descs)
             prep_descs.append(d)
 
+        # runs of FlowSteps that one launch can walk (same geometry, whole-image tiles): device array of their descriptors
+        runs = {}
+        if self.bf16 and not self.is_1d:
+            i = 0
+            while i < len(recs):
+                r = recs[i]
+                if r.kind == "step" and r.cs.wf1 and lib.nfk_run2d_fused_ok(C.byref(r.cs)):
+                    j = i
+                    while (j < len(recs) and recs[j].kind == "step" and j - i < 64 and recs[j].cs.wf1 and
+                           (recs[j].C, recs[j].H, recs[j].W, recs[j].hid, recs[j].Cout, recs[j].additive) ==
+                           (r.C, r.H, r.W, r.hid, r.Cout, r.additive)):
+                        j += 1
+                    if j - i >= 2:
+                        runs[i] = {"n": j - i, "dev": capi.struct_array_to_device([q.cs for q in recs[i:j]], device)}
+                    i = j
+                else:
+                    i += 1
+
         self.state = {
+            "runs": runs,
             "B": B, "recs": recs, "prep_buf": prep_buf, "pack_buf": pack_buf, "keep": keep,
             "prep_dev": capi.struct_array_to_device(prep_descs, device), "n_prep": len(prep_descs),
             "prep_host": prep_descs,
@@ -307,14 +329,22 @@ class FlowEngine:
         st["version"], st["has_inverse"] = ver, bool(want_inverse)
 
     # ------------------------------------------------------------------ public entry points
-    def encode(self, x, y_onehot, logdet, noise=None):
+    def encode(self, x, y_onehot, logdet, noise=None, keep=None):
+        """-> (list of every layer's output, logdet).  `keep` (optional, honoured by passes that record no gradient): the
+        layer indices whose outputs the caller will read (the KD hint layers of pl_module.py:262-282; negative indices
+        allowed; the last layer is always kept) -- the other entries of the list are None and never reach HBM where a
+        whole level runs as one launch."""
         if y_onehot is not None and not self.is_1d:
             # the reference concatenates a [B,classes] tensor to a 4-D one here (models/flows.py:153)
             raise RuntimeError("Tensors must have same number of dimensions: got 4 and 2")
         B = x.shape[0]
         if not torch.is_tensor(logdet):
             logdet = torch.full((B,), float(logdet), device=x.device, dtype=torch.float32)
-        res = _EncodeFn.apply(self, x, logdet, noise, y_onehot, *self.params())
+        if keep is not None:
+            n_layers = len(self.layers)
+            keep = frozenset(int(k) % n_layers for k in keep) | {n_layers - 1}
+        # (inside autograd.Function.forward the grad mode is always off: whether this pass records gradients is read here)
+        res = _EncodeFn.apply(self, x, logdet, noise, y_onehot, (keep, torch.is_grad_enabled()), *self.params())
         return list(res[:-1]), res[-1]
 
     def decode(self, z, y_onehot, temperature, eps=None):
@@ -497,12 +527,15 @@ class _EncodeFn(torch.autograd.Function):
     """All layers of a FlowNet, forward (models/kd_flows.py:42-53) and backward, as one autograd node."""
 
     @staticmethod
-    def forward(ctx, eng, x, logdet, noise, y_onehot, *params):
+    def forward(ctx, eng, x, logdet, noise, y_onehot, keep_and_mode, *params):
         st = eng._ensure(x)
         eng._refresh(st, False)
         lib, s = capi.lib(), capi.stream()
         B, dev = x.shape[0], x.device
-        need = any(ctx.needs_input_grad)
+        keep, grad_mode = keep_and_mode
+        need = grad_mode and any(ctx.needs_input_grad)   # under torch.no_grad() nothing is kept for a backward
+        if need:
+            keep = None   # a pass that will be differentiated keeps every layer's output
         ctx.set_materialize_grads(False)
         ctx.eng, ctx.need, ctx.B, ctx.st = eng, need, B, st
         ld = logdet.to(torch.float32).contiguous()
@@ -521,7 +554,67 @@ class _EncodeFn(torch.autograd.Function):
         scratch = _Scratch(st, dev)
         cur, cur_ld = None, None  # NHWC tensor of the running activation
         run, keep_alive = None, []
+        skip_until = 0
+        use_runs = eng.fused and eng.bf16 and (eng.fused_runs is True or (eng.fused_runs == "inference" and not need))
         for r in st["recs"]:
+            if r.idx < skip_until:
+                continue   # part of a run of steps that one launch has already walked
+            if r.kind == "step" and use_runs and r.idx in st["runs"] and run is None:
+                # ---- a whole level's FlowSteps in ONE launch (whole-image pixel tiles: z stays in LDS between the steps)
+                info = st["runs"][r.idx]
+                n = info["n"]
+                if cur is None:
+                    cur = _nhwc(x)
+                tiles = lib.nfk_step2d_fused_tiles(C.byref(r.cs))
+                M_ = B * r.H * r.W
+                zc, hc = _a4(M_ * r.C), _a4(M_ * r.Cout)
+                ldbuf = torch.empty(n * B * tiles, device=dev, dtype=torch.float32)
+                fr = capi.FusedRun()
+                fr.steps, fr.nsteps, fr.x, fr.ldx = info["dev"].data_ptr(), n, cur.data_ptr(), r.C
+                fr.ldpart = ldbuf.data_ptr()
+                if need:
+                    kept = list(range(n))
+                    zs_all = torch.empty(n * zc, device=dev, dtype=torch.float32)
+                    h_all = torch.empty(2 * n * M_ * r.hid, device=dev, dtype=torch.bfloat16)
+                    hs_all = torch.empty(n * hc, device=dev, dtype=torch.float32)
+                    mbytes = lib.nfk_step2d_mask_bytes(C.byref(r.cs)) if r.cs.wg1 else 0
+                    mk_all = torch.empty(n * mbytes, device=dev, dtype=torch.uint8) if mbytes else None
+                    fr.zsave, fr.zsave_stride = zs_all.data_ptr(), zc
+                    fr.h1save, fr.h2save, fr.h_stride = h_all.data_ptr(), h_all.data_ptr() + 2 * n * M_ * r.hid, M_ * r.hid
+                    fr.hsave, fr.hsave_stride = hs_all.data_ptr(), hc
+                    if mk_all is not None:
+                        fr.masksave, fr.mask_stride = mk_all.data_ptr(), mbytes
+                else:
+                    kept = [k for k in range(n) if keep is None or (r.idx + k) in keep or k == n - 1]
+                zo_all = torch.empty(len(kept) * zc, device=dev, dtype=torch.float32)
+                fr.zout, fr.zout_stride = zo_all.data_ptr(), zc
+                fr.keep = sum(1 << k for k in kept)
+                check(lib.nfk_run2d_fwd_fused(C.byref(fr), C.byref(r.cs), s), "nfk_run2d_fwd_fused")
+                ld_out = torch.empty_like(ld)
+                check(lib.nfk_ld_finish(ptr(ld), ptr(ldbuf), n, B, tiles, ptr(ld_out), s), "nfk_ld_finish")
+                ld = ld_out
+                keep_alive.append(ldbuf)
+                slot = 0
+                for k in range(n):
+                    out = None
+                    if k in kept:
+                        out = zo_all[slot * zc: slot * zc + M_ * r.C].view(B, r.H, r.W, r.C)
+                        slot += 1
+                    if need:
+                        h1 = h_all[k * M_ * r.hid: (k + 1) * M_ * r.hid]
+                        h2 = h_all[(n + k) * M_ * r.hid: (n + k + 1) * M_ * r.hid]
+                        masks = mk_all[k * mbytes: (k + 1) * mbytes] if mk_all is not None else None
+                        saved.append((cur, zs_all[k * zc: k * zc + M_ * r.C], h1, h2, hs_all[k * hc: k * hc + M_ * r.Cout],
+                                      None, masks))
+                    else:
+                        saved.append(None)
+                    # (the run's last output always exists -- the next layer reads it -- but is only handed out if asked for)
+                    handed = out is not None and (keep is None or (r.idx + k) in keep)
+                    outs.append(out.permute(0, 3, 1, 2) if handed else None)
+                    if out is not None:
+                        cur = out
+                skip_until = r.idx + n
+                continue
             if r.kind == "squeeze":
                 out = torch.empty((B, r.H // 2, r.W // 2, 4 * r.C), device=dev, dtype=torch.float32)
                 if cur is None:
@@ -569,7 +662,7 @@ class _EncodeFn(torch.autograd.Function):
                 ways = eng.fused_split_training if need else eng.fused_split_inference
                 if ways == "frugal":   # beside another chain: only the grids that would fill fewer than 32 CUs
                     ways = 4 if (B * r.H * r.W + 63) // 64 < 32 else 0
-                lib.nfk_fused_set_split(int(ways))   # host-side launch parameter
+                ways = int(ways)
                 nws = lib.nfk_step2d_fused_ws_floats(C.byref(r.cs)) if ways else 0
                 ws = None
                 if nws:   # hidden-split step: partial conv3 slabs + (always) the mixed z for the coupling launch
@@ -579,7 +672,7 @@ class _EncodeFn(torch.autograd.Function):
                         (ws,) = scratch.get(nws)
                 part = run["buf"].data_ptr() + 4 * run["k"] * B * tiles
                 check(lib.nfk_step2d_fwd_fused(C.byref(r.cs), ptr(cur), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs), ptr(out),
-                                               part, ptr(ws), ptr(masks), s), "nfk_step2d_fwd_fused")
+                                               part, ptr(ws), ptr(masks), ways, s), "nfk_step2d_fwd_fused")
                 run["k"] += 1
                 if run["k"] == run["n"]:
                     ld_out = torch.empty_like(ld)
@@ -623,7 +716,7 @@ class _EncodeFn(torch.autograd.Function):
                 saved.append((cur, hs) if need else None)
                 ld = ld_out
             cur = out
-            outs.append(out.permute(0, 3, 1, 2))
+            outs.append(out.permute(0, 3, 1, 2) if (keep is None or r.idx in keep) else None)
             if r is st["recs"][0] and eng.first_layer_hook is not None:
                 eng.first_layer_hook()  # the model input has been consumed (and dequantised in place)
         ctx.saved = saved
@@ -641,7 +734,7 @@ class _EncodeFn(torch.autograd.Function):
         if g_ld is None:
             g_ld = torch.zeros(B, device=dev, dtype=torch.float32)
         g_ld = g_ld.to(torch.float32).contiguous()
-        n_in = 5 + len(eng.params())
+        n_in = 6 + len(eng.params())
         # make sure every parameter has a grad buffer the kernels can accumulate into
         for p in eng.params():
             if p.requires_grad and p.grad is None:

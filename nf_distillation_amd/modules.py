@@ -313,8 +313,8 @@ class FlowNet(nn.Module):
             self._engine = FlowEngine(list(self.layers))
         return self._engine
 
-    def _encode_all(self, z, y_onehot, logdet, noise=None):
-        return self.engine().encode(z, y_onehot, logdet, noise)
+    def _encode_all(self, z, y_onehot, logdet, noise=None, keep=None):
+        return self.engine().encode(z, y_onehot, logdet, noise, keep)
 
     def _decode_all(self, z, y_onehot, temperature, eps=None):
         return self.engine().decode(z, y_onehot, temperature, eps)
@@ -400,12 +400,18 @@ class Glow(nn.Module):
         h = self._prior_tensor(batch, y_onehot)
         return split_feature(h, "split")
 
-    def forward(self, x=None, y_onehot=None, z=None, temperature=None, reverse=False, noise=None, eps=None):
+    def forward(self, x=None, y_onehot=None, z=None, temperature=None, reverse=False, noise=None, eps=None, keep=None):
+        """The reference's signature (models/flows.py:393-397) plus three optional extensions: `noise` / `eps` supply the
+        dequantisation / Split2d draws, `keep` (no-grad passes) names the layer outputs the caller will read -- the KD hint
+        indices of pl_module.py:262-282 -- so that the others are neither kept nor, where a level runs as one launch,
+        written to HBM at all (their entries in the returned list are None; the last layer is always there)."""
         if reverse:
             return self.reverse_flow(z, y_onehot, temperature, eps=eps)
+        if keep is not None:
+            return self.normal_flow(x, y_onehot, noise=noise, keep=keep)
         return self.normal_flow(x, y_onehot, noise=noise)
 
-    def _forward_all(self, x, y_onehot, noise):
+    def _forward_all(self, x, y_onehot, noise, keep=None):
         """Shared by Glow / GlowGetAllOutputs: returns (all outputs, bpd, y_logits)."""
         from .engine import prior_bpd
         capi.require_cuda(x, "x")
@@ -421,7 +427,7 @@ class Glow(nn.Module):
                 noise = torch.empty_like(x).uniform_(0, 1.0 / 256)
             logdet = torch.full((b,), -math.log(256.0) * c * h * w, device=x.device, dtype=torch.float32)
             dims = c * h * w
-        outs, objective_ld = self.flow._encode_all(x, y_onehot, logdet, noise)
+        outs, objective_ld = self.flow._encode_all(x, y_onehot, logdet, noise, keep)
         last = outs[-1]
         prior_t = self._prior_tensor(b, y_onehot)
         scale = 1.0 if self.is_1d else 1.0 / (math.log(2.0) * dims)
@@ -465,8 +471,8 @@ class GlowGetAllOutputs(Glow):
 
     _flow_cls = FlowNetGetAllOutputs
 
-    def normal_flow(self, x, y_onehot=None, noise=None):
-        return self._forward_all(x, y_onehot, noise)
+    def normal_flow(self, x, y_onehot=None, noise=None, keep=None):
+        return self._forward_all(x, y_onehot, noise, keep)
 
 
 def create_glow_model(config):

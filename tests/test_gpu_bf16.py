@@ -83,22 +83,16 @@ def test_distillation_step_trains():
     assert float(out["result_loss"]) < first
 
 
-@pytest.mark.parametrize("dbg", [0, 0x400, 0x300], ids=["policy", "no_hidden_split", "gen1_forced"])
+@pytest.mark.parametrize("ways", [4, 0, 2], ids=["split4", "no_hidden_split", "split2"])
 @pytest.mark.parametrize("name", ["cifar_k8_full", "glow32"])
-def test_fused_step_equals_unfused(name, dbg):
-    """The one-launch FlowStep forward (csrc/nfk_fused2.hip; generation 1 in nfk_fused.hip) against the five-kernel
-    bf16 path: same bf16 roundings of h1/h2/weights, so outputs agree to fp32 summation-order noise; gradients (same
-    backward) likewise.  `dbg` bit 8 forces generation 1 where its policy would not pick it (levels 2 and 3), bit 9 selects
-    generation 1, bit 10 switches off the hidden split generation 2 uses on small grids."""
-    from nf_distillation_amd import capi
-    capi.lib().nfk_fused_set_debug(dbg)
-    try:
-        _fused_vs_unfused(name)
-    finally:
-        capi.lib().nfk_fused_set_debug(0)
+def test_fused_step_equals_unfused(name, ways):
+    """The one-launch FlowStep forward (csrc/nfk_fused2.hip) against the five-kernel bf16 path: same bf16 roundings of
+    h1/h2/weights, so outputs agree to fp32 summation-order noise; gradients (same backward) likewise.  `ways`: the hidden
+    split the fused launch uses on small grids (CIFAR levels 2 / 3): 4-way (default policy), none, 2-way."""
+    _fused_vs_unfused(name, ways)
 
 
-def _fused_vs_unfused(name):
+def _fused_vs_unfused(name, ways=4):
     g = Golden(name)
     cfg = g.cfg
     if name.endswith("_full"):
@@ -107,13 +101,14 @@ def _fused_vs_unfused(name):
         x, noise = synthetic_images(int(g.t("batch")), (c, h, w), seed=int(g.t("seed")) + 5)
     else:
         sd, x, noise = g.group("sd"), g.t("x"), g.t("noise")
-    _compare_fused_unfused(cfg, sd, x, noise)
+    _compare_fused_unfused(cfg, sd, x, noise, ways=ways)
 
 
-def _compare_fused_unfused(cfg, sd, x, noise, seed=None):
+def _compare_fused_unfused(cfg, sd, x, noise, seed=None, ways=4):
     res = []
     for fused in (True, False):
         model = build(cfg, sd, seed).set_fused(fused)
+        model.flow.engine().fused_split_training = ways
         outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
         bpd.mean().backward()
         torch.cuda.synchronize()

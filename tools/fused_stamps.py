@@ -14,19 +14,18 @@ from nf_distillation_amd.engine import FlowEngine  # noqa: E402
 from param_util import synthetic_images  # noqa: E402
 
 dev = torch.device("cuda", 0)
-student, teacher = bench.make_models(dev)
+student, teacher = bench.make_models(dev, "bf16")
 x = synthetic_images(64, seed=1)[0].to(dev)
 lib = capi.lib()
 names = ["mix", "im2col", "conv1", "conv2+3 chunks", "tail"]
 CASES = []
-for gen, base in (("gen2", 0x100), ("gen1", 0x300)):
+for ways in (0, 4):
     for nlayers, level in ((2, 1), (35, 2), (69, 3)):
-        CASES.append((base, nlayers, f"{gen} level {level}"))
-CASES += [(0x301, 2, "gen1 level 1, no in-loop weight loads"), (0x302, 2, "gen1 level 1, no conv3")]
-for dbg, nlayers, label in CASES:
-    lib.nfk_fused_set_debug(dbg)
+        CASES.append((ways, nlayers, f"level {level}, hidden split {ways}"))
+for ways, nlayers, label in CASES:
     e = FlowEngine(list(teacher.flow.layers)[:nlayers])
     e.set_compute_dtype("bf16")
+    e.fused_split_inference = ways
     buf = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
     ld = torch.zeros(64, device=dev)
     with torch.no_grad():
@@ -36,7 +35,6 @@ for dbg, nlayers, label in CASES:
         e.encode(x.clone(), None, ld)
         torch.cuda.synchronize()
         lib.nfk_fused_set_stamps(None)
-    lib.nfk_fused_set_debug(0)
     st = buf.view(-1, 16).cpu()
     st = st[st[:, 0] != 0]
     d = (st[:, 1:6] - st[:, 0:5]).double()

@@ -15,20 +15,20 @@ from nf_distillation_amd.engine import FlowEngine  # noqa: E402
 from param_util import synthetic_images  # noqa: E402
 
 dev = torch.device("cuda", 0)
-student, teacher = bench.make_models(dev)
+student, teacher = bench.make_models(dev, "bf16")
 x = synthetic_images(64, seed=1)[0].to(dev)
 lib = capi.lib()
 layers = list(teacher.flow.layers)
 # teacher: [squeeze, 32 steps, split, squeeze, 32 steps, split, squeeze, 32 steps]
 spans = {"level 1": (0, 33), "level 2": (0, 67), "level 3": (0, 101)}
 prev = 0.0
-for label, fused, dbg in (("5-kernel", False, 0), ("fused gen1", True, 0x300), ("fused gen2", True, 0x100)):
-    lib.nfk_fused_set_debug(dbg)   # bit 8: force the fused step also for small grids, bit 9: generation 1
+for label, fused, ways in (("5-kernel", False, 0), ("fused, no hidden split", True, 0), ("fused, 4-way hidden split", True, 4)):
     prev_t = 0.0
     for name, (a, b) in spans.items():
         e = FlowEngine(layers[a:b])
         e.set_compute_dtype("bf16")
         e.fused = fused
+        e.fused_split_inference = ways
         ld = torch.zeros(64, device=dev)
         with torch.no_grad():
             for _ in range(3):
@@ -44,4 +44,3 @@ for label, fused, dbg in (("5-kernel", False, 0), ("fused gen1", True, 0x300), (
         print(f"{label} {name}: cumulative {ms:.3f} ms, this level {ms - prev_t:.3f} ms "
               f"= {(ms - prev_t) / 32 * 1e3:.1f} us/step", flush=True)
         prev_t = ms
-lib.nfk_fused_set_debug(0)
