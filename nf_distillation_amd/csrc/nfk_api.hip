@@ -15,8 +15,11 @@ int splitk_of(int bf16, int M, int N, int K);
   } while (0)
 
 struct StepBwdWs {
-  size_t ga3, gz, ga2, ga1, d1slab, col2, col1, tail, wslab, total;
+  size_t ga3, gz, ga2, ga1, d1slab, col2, col1, tail, wslab, x3, total;
   int S1, S3w, S2w, S1w, mb1, mb2;
+  // fused backward: conv3's / conv1's weight gradients as plain GEMMs on the im2col rows the fused kernels leave
+  // (P = x3 [M][K3p] from nfk_fusedb.hip, Q = x1 [M][K1p] from nfk_fused2.hip): their split counts and row lengths
+  int S3f, S1f, K3p, K1p;
   size_t ws3, ws2;   // sizes of the first two weight-gradient slab regions inside wslab
 };
 StepBwdWs step_bwd_layout(const nfk_step2d* s) {
@@ -30,9 +33,14 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   // column-sum partials of the two dgrad epilogues: one row pair per m-block of THAT launch's tiling
   w.mb2 = s->bf16 ? conv_mblocks_bf16((int)M, hid, 9 * s->Cout) : conv_mblocks((int)M, hid);   // conv3 dgrad -> col2
   w.mb1 = s->bf16 ? conv_mblocks_bf16((int)M, hid, hid) : conv_mblocks((int)M, hid);           // conv2 dgrad -> col1
-  const int fg = (s->bf16 && fusedb_grid(*s) > 0) ? actnorm_sum_parts((int)M) : 0;   // the fused backward's partial rows
+  const bool fused = s->bf16 && fusedb_grid(*s) > 0;
+  const int fg = fused ? actnorm_sum_parts((int)M) : 0;   // the fused backward's partial rows
   if (fg > w.mb2) w.mb2 = fg;
   if (fg > w.mb1) w.mb1 = fg;
+  w.K3p = fused ? fusedb_k3p(*s) : 0;
+  w.K1p = fused ? fused2_k1p(*s) : 0;
+  w.S3f = fused ? wgrad_splits_bf16((int)M, w.K3p, hid) : 0;
+  w.S1f = fused ? wgrad_splits_bf16((int)M, hid, w.K1p) : 0;
   size_t o = 0;
   w.ga3 = o; o += align4(M * s->Cout);
   w.gz = o; o += align4(M * s->C);
@@ -44,9 +52,12 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   // coupling-tail partial rows: one per sample, or one per channel-mix workgroup of the previous step (chained backward)
   w.tail = o; o += align4((size_t)(s->B > 256 ? s->B : 256) * 2 * s->Cout);
   // the three weight gradients' split slabs, each in a region of its own (reduced together by step_tail_kernel)
-  w.ws3 = align4((size_t)w.S3w * s->Cout * 9 * hid);
+  const size_t e3 = (size_t)w.S3w * s->Cout * 9 * hid, e3f = (size_t)w.S3f * w.K3p * hid;
+  const size_t e1 = (size_t)w.S1w * hid * 9 * Ch, e1f = (size_t)w.S1f * hid * w.K1p;
+  w.ws3 = align4(e3 > e3f ? e3 : e3f);
   w.ws2 = align4((size_t)w.S2w * hid * hid);
-  w.wslab = o; o += w.ws3 + w.ws2 + align4((size_t)w.S1w * hid * 9 * Ch);
+  w.wslab = o; o += w.ws3 + w.ws2 + align4(e1 > e1f ? e1 : e1f);
+  w.x3 = o; o += align4((M * w.K3p + 1) / 2);   // bf16 [M][K3p]
   w.total = o;
   return w;
 }
@@ -338,18 +349,28 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
     FusedBwdCall fc{};
     fc.s = *s; fc.ga3 = ga3; fc.masks = reinterpret_cast<const unsigned char*>(g->relu_masks);
     fc.ga2 = ga2; fc.ga1 = ga1; fc.d1 = d1; fc.stamps = g_bwd_stamps;
+    fc.x3save = ws + L.x3;
     NFK_TRY(fusedb_launch(fc, st));
+    // conv3 and conv1 as plain pixel-major GEMMs: the 3x3 taps sit in the im2col rows the two fused kernels built anyway
+    // (dgrad3's of g_a3 above, conv1's of z1 behind the ReLU masks of the forward), not in nine shifted passes / a
+    // per-element gather:  gW3[co][ci][tap] = sum_m x3[m][(8 - tap) Cout + co] h2[m][ci],
+    //                      gW1[co][ci][tap] = sum_m g_a1[m][co] x1[m][tap C/2 + ci]
+    w3.P = ws + L.x3; w3.ldp = L.K3p; w3.NI = L.K3p; w3.pbf16 = 1; w3.taps = 1; w3.slab_stride = (long)L.K3p * hid;
+    w1.Q = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(g->relu_masks) + (size_t)2 * M * (hid / 8));
+    w1.ldq = L.K1p; w1.Cq = L.K1p; w1.taps = 1; w1.qbf16 = 1; w1.slab_stride = (long)hid * L.K1p;
     ActnormSumArgs an{};
     an.ga2 = ga2; an.h2 = h2; an.ga1 = ga1; an.h1 = h1; an.es2 = s->es2; an.es1 = s->es1; an.col2 = col2; an.col1 = col1;
     an.M = M; an.hid = hid; an.nparts = actnorm_sum_parts(M);
     mb1 = mb2 = an.nparts;
-    NFK_TRY(triple_wgrad_bf16(w3, L.S3w, w2, L.S2w, w1, L.S1w, an, st));
+    NFK_TRY(triple_wgrad_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an, st, (double)hid * (9.0 * Cout + hid + 9.0 * Ch)));
     const WgradArgs* ws3[3] = {&w3, &w2, &w1};
-    const int Sw[3] = {L.S3w, L.S2w, L.S1w}, Co[3] = {Cout, hid, hid}, Ci[3] = {hid, hid, Ch}, tp[3] = {9, 1, 9};
+    const int Sw[3] = {L.S3f, L.S2w, L.S1f}, Co[3] = {Cout, hid, hid}, Ci[3] = {hid, hid, Ch}, tp[3] = {9, 1, 9};
+    const int md[3] = {1, 0, 0}, lj[3] = {hid, 0, L.K1p};
     float* gw[3] = {g->g_w3, g->g_w2, g->g_w1};
     for (int k = 0; k < 3; ++k) {
       tail_f.slabs[k] = ws3[k]->out; tail_f.gradW[k] = gw[k]; tail_f.stride[k] = ws3[k]->slab_stride;
       tail_f.S[k] = Sw[k]; tail_f.Cout[k] = Co[k]; tail_f.Cin[k] = Ci[k]; tail_f.taps[k] = tp[k];
+      tail_f.mode[k] = md[k]; tail_f.ldj[k] = lj[k];
     }
   }
 
@@ -429,7 +450,10 @@ size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d* s) {
 void* nfk_get_aux_stream(void) { return g_aux; }
 void nfk_fused_bwd_set_stamps(void* buf) { g_bwd_stamps = reinterpret_cast<unsigned long long*>(buf); }
 int nfk_step2d_fused_bwd_ok(const nfk_step2d* s) { return (s->bf16 && g_bwd_mode == 3 && fusedb_grid(*s) > 0) ? 1 : 0; }
-size_t nfk_step2d_mask_bytes(const nfk_step2d* s) { return (size_t)2 * s->B * s->H * s->W * (s->hidden / 8); }
+size_t nfk_step2d_mask_bytes(const nfk_step2d* s) {
+  const size_t M = (size_t)s->B * s->H * s->W;
+  return 2 * M * (s->hidden / 8) + M * fused2_k1p(*s) * 2;   // ReLU masks of h1 / h2, then conv1's im2col rows (bf16)
+}
 void nfk_set_bwd_mode(int mode) { g_bwd_mode = mode; }
 int nfk_aux_join(void* stream) {
   hipStream_t st = S_(stream);

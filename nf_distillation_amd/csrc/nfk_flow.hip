@@ -1058,10 +1058,12 @@ __device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const Ste
   const int total = f.Cout[k] * J;
   const float* slabs = f.slabs[k];
   float* gw = f.gradW[k];
+  const int ldj = f.ldj[k] ? f.ldj[k] : J, mode = f.mode[k];
   for (int t = b * 256 + threadIdx.x; t < total; t += f.blocks[k] * 256) {
     const int r = t / taps, tap = t - r * taps;
     const int co = r / Cin, ci = r - co * Cin;
-    gw[t] += slab_sum(slabs, S, f.stride[k], (long)co * J + tap * Cin + ci);
+    const long off = mode == 1 ? (long)((taps - 1 - tap) * f.Cout[k] + co) * ldj + ci : (long)co * ldj + tap * Cin + ci;
+    gw[t] += slab_sum(slabs, S, f.stride[k], off);
   }
 }
 

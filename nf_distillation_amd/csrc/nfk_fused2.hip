@@ -268,6 +268,10 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       xreg[i] = xb[(long)pix * a.c.ldx + ch];
     }
     load_params(sp);
+    // conv1's weight fragments travel during the mix and the im2col; their requests (up to 32 KiB per wave: ~2 k cycles
+    // of issue for the four waves) go out while x and the parameters are still on their way
+#pragma unroll
+    for (int j = 0; j < W1R; ++j) load_w1(r1, j, w1[j]);
 #pragma unroll
     for (int i = 0; i < XMAX; ++i) {
       const int e = tid + 256 * i;
@@ -276,10 +280,9 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     store_params();
   } else {
     store_params();   // requested before the previous step's tail
-  }
-  // conv1's weight fragments travel during the mix and the im2col
 #pragma unroll
-  for (int j = 0; j < W1R; ++j) load_w1(r1, j, w1[j]);
+    for (int j = 0; j < W1R; ++j) load_w1(r1, j, w1[j]);
+  }
   stamp(8);
   __syncthreads();
   stamp(9);
@@ -372,6 +375,21 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   }
   __syncthreads();
   stamp(2);
+  if (c_masksave && qs == 0) {
+    // training forward: the im2col rows of the tile's own pixels (bf16 [M][K1p], behind the ReLU masks in `masksave`) are
+    // the Q operand of conv1's weight gradient -- a plain pixel-major GEMM operand instead of a 9-tap gather from z
+    __bf16* x1g = reinterpret_cast<__bf16*>(c_masksave + (long)2 * s.B * HW * (HID / 8));
+    constexpr int PPR = K1M * 2;   // 16-byte pieces per row
+    for (int p = tid; p < 64 * PPR; p += 256) {
+      const int po = p / PPR, slot = p % PPR;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+      const int b = b0 + sm;
+      if (b >= s.B) continue;
+      const int ph = sm * g.RH * W + (rr + halo) * W + xx;
+      const long m = (long)b * HW + (row0 + rr) * W + xx;
+      *reinterpret_cast<u32x4f*>(x1g + m * (K1M * 16) + slot * 8) = *reinterpret_cast<const u32x4f*>(X1 + ph * g.X1S + slot * 16);
+    }
+  }
 
   // this lane's h-region pixel in each 32-pixel tile: inside the image?  (conv3's zero padding is applied to h2)
   unsigned hmask[MT32];
@@ -823,6 +841,8 @@ int fused2_tiles(const nfk_step2d& s) {
   if (!inst) return 0;
   return a.TS == 1 ? s.H / a.R : 1;
 }
+
+int fused2_k1p(const nfk_step2d& s) { return (9 * (s.C / 2) + 63) / 64 * 64; }
 
 size_t fused2_ws_floats(const nfk_step2d& s) {
   F2Args a{};

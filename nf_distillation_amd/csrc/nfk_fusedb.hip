@@ -208,6 +208,22 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   }
   __syncthreads();
   stamp(2);
+  if (a.c.x3save) {
+    // the im2col rows of the tile's own pixels, bf16 [M][K3p]: X3[m][tap * Cout + co] = g_a3[m + d(tap)][co] is, with the
+    // taps flipped, the P operand of conv3's weight gradient as a plain pixel-major GEMM (sum_m X3[m][(8 - tap) Cout + co]
+    // h2[m][ci]) -- instead of nine shifted passes over the 512-wide h2
+    __bf16* x3g = reinterpret_cast<__bf16*>(a.c.x3save);
+    constexpr int PPR = K3M * 2;   // 16-byte pieces per row
+    for (int p = tid; p < 64 * PPR; p += 256) {
+      const int po = p / PPR, slot = p % PPR;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+      const int b = b0 + sm;
+      if (b >= s.B) continue;
+      const int ph = sm * g.RH * W + (rr + halo) * W + xx;
+      const long m = (long)b * HW + (row0 + rr) * W + xx;
+      *reinterpret_cast<u32x4f*>(x3g + m * g.K3p + slot * 8) = *reinterpret_cast<const u32x4f*>(X3 + ph * g.X3S + slot * 16);
+    }
+  }
 
   // ReLU / ActNorm backward of one accumulator tile (32 channels x 32 pixels per m-tile) into the image:
   //   g_a = (h > 0) ? g e^logs : 0, bit (8*gi + 4*hi + r) of `word` = (h > 0) for channel n0 - 4*hi + 8*gi + 4*hi + r
@@ -491,6 +507,8 @@ int fusedb_grid(const nfk_step2d& s) {
   if (!fb_pick(s, &a)) return 0;
   return a.TS == 1 ? s.B * (s.H / a.R) : (s.B + a.TS - 1) / a.TS;
 }
+
+int fusedb_k3p(const nfk_step2d& s) { return (9 * s.Cout + 63) / 64 * 64; }
 
 int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
   FBArgs a{};

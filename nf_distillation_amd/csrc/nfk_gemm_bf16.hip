@@ -956,30 +956,34 @@ __device__ __forceinline__ void actnorm_sum_body(const ActnormSumArgs& a, const 
 }
 
 // The three weight-gradient GEMMs of one FlowStep in ONE launch (the fused backward, nfk_fusedb.hip, has produced all
-// three output gradients by then): conv2's 512x512 tiles first (the longest workgroups), then conv1's, then conv3's,
-// then the ActNorm sums (bandwidth work beside latency-bound GEMMs).
-// V3: body of conv3's narrow weight gradient -- 0 = the halo-tile kernel, 1..3 = the generic body with V3 row tiles.
+// three output gradients by then).  Block order: the ActNorm sums first (64 workgroups of pure streaming: started last
+// they were the tail of the launch), then conv2's 512x512 tiles (the longest GEMM workgroups), conv3's, conv1's.
+// V3: body of conv3's weight gradient -- 4 = the wide GEMM body on dgrad3's im2col rows (P = [M][9 Cout padded], taps
+// folded into P: see nfk_api.hip), 0 = the halo-tile kernel, 1..3 = the generic narrow body with V3 row tiles.
 template <int V3>
 __global__ void __launch_bounds__(256) triple_wgrad_bf16_kernel(WgradArgs w2, int nb2, int S2, WgradArgs w1, int nb1, int S1,
                                                                 WgradArgs w3, int nb3, int S3, int n3, ActnormSumArgs an) {
   int b = blockIdx.x;
+  if (b < an.nparts) { actnorm_sum_body(an, b); return; }
+  b -= an.nparts;
   if (b < nb2 * S2) { wgrad_bf16_body<4, 4, 2, 2>(w2, b % nb2, S2, b / nb2); return; }
   b -= nb2 * S2;
-  if (b < nb1 * S1) { wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1); return; }
-  b -= nb1 * S1;
   if (b < n3) {
-    if (V3 == 0) wgrad_halo_body(w3, b, S3);
-    else wgrad_bf16_body<(V3 > 0 ? V3 : 1), 2, 1, 4>(w3, b % nb3, S3, b / nb3);
+    if (V3 == 4) wgrad_bf16_body<4, 4, 2, 2>(w3, b % nb3, S3, b / nb3);
+    else if (V3 == 0) wgrad_halo_body(w3, b, S3);
+    else wgrad_bf16_body<((V3 > 0 && V3 < 4) ? V3 : 1), 2, 1, 4>(w3, b % nb3, S3, b / nb3);
     return;
   }
-  actnorm_sum_body(an, b - n3);
+  b -= n3;
+  wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1);
 }
 
 template <int V3>
 static int launch_triple(const WgradArgs& w3, int S3, const WgradArgs& w2, int S2, const WgradArgs& w1, int S1,
-                         const ActnormSumArgs& an, hipStream_t st) {
+                         const ActnormSumArgs& an, hipStream_t st, double alg_nj) {
   constexpr size_t ldsWide = 2 * WPX * (wg_stride(128) + wg_stride(128));
-  const size_t lds3 = V3 == 0 ? wh_lds_bytes(w3.W) : 2 * WPX * (wg_stride(16 * (V3 > 0 ? V3 : 1)) + wg_stride(128));
+  const size_t lds3 = V3 == 4 ? ldsWide
+                              : (V3 == 0 ? wh_lds_bytes(w3.W) : 2 * WPX * (wg_stride(16 * ((V3 > 0 && V3 < 4) ? V3 : 1)) + wg_stride(128)));
   const size_t lds = ldsWide > lds3 ? ldsWide : lds3;   // (the ActNorm sums need 32 KiB)
   static bool attr = false;
   if (!attr) {
@@ -989,10 +993,14 @@ static int launch_triple(const WgradArgs& w3, int S3, const WgradArgs& w2, int S
   }
   if (lds > 80 * 1024 || an.hid != 512 || an.nparts < 1) return NFK_ERR_ARG;
   const int nb2 = ceil_div(w2.NI, 128) * ceil_div(w2.J, 128), nb1 = ceil_div(w1.NI, 128) * ceil_div(w1.J, 128);
-  const int nb3 = V3 == 0 ? (w3.Cq / 128) * S3 : ceil_div(w3.NI, 16 * (V3 > 0 ? V3 : 1)) * ceil_div(w3.J, 128);
+  const int nb3 = V3 == 4 ? ceil_div(w3.NI, 128) * ceil_div(w3.J, 128)
+                          : (V3 == 0 ? (w3.Cq / 128) * S3 : ceil_div(w3.NI, 16 * ((V3 > 0 && V3 < 4) ? V3 : 1)) * ceil_div(w3.J, 128));
   const int n3 = V3 == 0 ? nb3 : nb3 * S3;
   const int cls = NFK_PROF_TRIPLE_WGRAD + (w2.M >= 8192 ? 0 : (w2.M >= 2048 ? 1 : 2));
-  prof_scope_begin(cls, 2.0 * w2.M * ((double)w2.NI * w2.J + (double)w1.NI * w1.J + (double)w3.NI * w3.J),
+  // algorithmic work (bench.py roofline leg): `alg_nj` = sum over the three convs of Cout * Cin * taps when the operands
+  // carry padding (im2col rows), else from the arguments
+  const double nj = alg_nj > 0 ? alg_nj : ((double)w2.NI * w2.J + (double)w1.NI * w1.J + (double)w3.NI * w3.J);
+  prof_scope_begin(cls, 2.0 * w2.M * nj,
                    w2.M * (2.0 * w2.NI + 2.0 * w2.Cq + 2.0 * w1.NI + 4.0 * w1.Cq + 4.0 * w3.NI + 2.0 * w3.Cq) +
                        4.0 * (S2 * (double)w2.NI * w2.J + S1 * (double)w1.NI * w1.J + S3 * (double)w3.NI * w3.J), st);
   hipLaunchKernelGGL((triple_wgrad_bf16_kernel<V3>), dim3(nb2 * S2 + nb1 * S1 + n3 + an.nparts), dim3(256), lds, st, w2, nb2,
@@ -1003,20 +1011,25 @@ static int launch_triple(const WgradArgs& w3, int S3, const WgradArgs& w2, int S
 }
 
 int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an,
-                      hipStream_t st) {
+                      hipStream_t st, double alg_nj) {
   for (WgradArgs* w : {&w3, &w2, &w1}) {
     w->M = w->B * w->H * w->W;
     w->J = w->taps * w->Cq;
     if (w->M <= 0 || w->NI <= 0 || w->J <= 0) return NFK_ERR_ARG;
     if ((long)w->M * w->ldp * 4 >= 0x7fffffffL || (long)w->M * w->ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
   }
-  if (w2.NI <= 96 || w1.NI <= 96 || w3.NI > 48 || !w2.pbf16 || !w2.qbf16 || !w1.pbf16) return NFK_ERR_ARG;
+  if (w2.NI <= 96 || w1.NI <= 96 || !w2.pbf16 || !w2.qbf16 || !w1.pbf16) return NFK_ERR_ARG;
+  if (w3.taps == 1 && w3.pbf16) {   // conv3 through dgrad3's im2col rows (taps folded into P): a plain GEMM like the other two
+    if (!w3.qbf16 || ((w3.NI | w3.ldp | w3.Cq | w3.ldq) & 7)) return NFK_ERR_ARG;
+    return launch_triple<4>(w3, S3, w2, S2, w1, S1, an, st, alg_nj);
+  }
+  if (w3.NI > 48) return NFK_ERR_ARG;
   if (!w3.pbf16 && w3.qbf16 && wgrad_halo_usable(w3.M, w3.NI, w3.Cq, w3.taps, w3.W) && S3 == wgrad_halo_splits(w3.M))
-    return launch_triple<0>(w3, S3, w2, S2, w1, S1, an, st);
+    return launch_triple<0>(w3, S3, w2, S2, w1, S1, an, st, alg_nj);
   switch (ceil_div(w3.NI, 16)) {
-    case 1: return launch_triple<1>(w3, S3, w2, S2, w1, S1, an, st);
-    case 2: return launch_triple<2>(w3, S3, w2, S2, w1, S1, an, st);
-    case 3: return launch_triple<3>(w3, S3, w2, S2, w1, S1, an, st);
+    case 1: return launch_triple<1>(w3, S3, w2, S2, w1, S1, an, st, alg_nj);
+    case 2: return launch_triple<2>(w3, S3, w2, S2, w1, S1, an, st, alg_nj);
+    case 3: return launch_triple<3>(w3, S3, w2, S2, w1, S1, an, st, alg_nj);
   }
   return NFK_ERR_ARG;
 }

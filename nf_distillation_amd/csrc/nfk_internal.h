@@ -130,6 +130,7 @@ struct FusedBwdCall {
   void* ga2;             // [M][hid] bf16 out: operand of conv2's weight gradient
   void* ga1;             // [M][hid] bf16 out: operand of conv1's weight gradient
   float* d1;             // [M][C/2] out: dgrad1 (added to g_z1 by the channel-mix backward)
+  void* x3save;          // [M][fusedb_k3p(s)] bf16 out (or null): dgrad3's im2col rows = P operand of conv3's weight gradient
   unsigned long long* stamps;  // diagnostic: [grid][16] cycle stamps (null in production)
 };
 // per-channel sums behind the two ActNorm layers' gradients, over a range of pixels (a 4th body of the triple launch):
@@ -143,8 +144,11 @@ struct ActnormSumArgs {
 int actnorm_sum_parts(int M);
 int fusedb_grid(const nfk_step2d& s);    // workgroups (= partial rows in col1 / col2) of the fused backward, 0 = not supported
 int fusedb_launch(const FusedBwdCall& c, hipStream_t st);
+int fusedb_k3p(const nfk_step2d& s);     // row length of x3save: 9 * Cout rounded up to 64
+int fused2_k1p(const nfk_step2d& s);     // row length of the im2col rows the fused forward leaves behind the masks
 // the three weight-gradient GEMMs of a step (block.4, .2, .0) in ONE launch; NFK_ERR_ARG: shapes not instantiated
-int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an, hipStream_t st);
+int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an, hipStream_t st,
+                      double alg_nj = 0.0);
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 int fused2_launch(const FusedCall& c, hipStream_t st);
 size_t fused2_ws_floats(const nfk_step2d& s);
@@ -203,6 +207,9 @@ struct StepTailArgs {
   const float* slabs[3]; float* gradW[3];
   long stride[3];
   int S[3], Cout[3], Cin[3], taps[3];
+  // layout of a slab: mode 0: [Cout][ldj] with column tap * Cin + ci (ldj = 0: taps * Cin);
+  //                   mode 1: [taps * Cout -> rows (taps - 1 - tap) * Cout + co][ldj] with column ci (conv3 through dgrad3's im2col)
+  int mode[3], ldj[3];
   int blocks[3], sg_blocks;   // filled by the launcher
 };
 int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st);
