@@ -98,6 +98,8 @@ class Leg:
         from nf_distillation_amd.training import DistillationStep
         self.args, self.dtype, self.data, self.world = args, dtype, data, world
         self.student, self.teacher = make_models(device, dtype)
+        if getattr(args, "bwd_mode", None) is not None:
+            self.student.flow.engine().bwd_mode = args.bwd_mode
         if args.fused_runs is not None:
             self.teacher.flow.engine().fused_runs = args.fused_runs in ("both", "teacher")
             self.student.flow.engine().fused_runs = args.fused_runs in ("both", "student")
@@ -263,9 +265,10 @@ def main():
     ap.add_argument("--fused-runs", choices=("both", "teacher", "student", "off"), default=None,
                     help="experiment knob: which model walks a whole level's FlowSteps in ONE launch (levels 2 / 3; "
                          "default: the engines' default)")
-    ap.add_argument("--tuning", type=int, default=None, help="experiment knob: nfk_set_tuning(v)")
-    ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_set_bwd_mode(v) (0: dgrad and wgrad as "
-                                                                 "separate launches, 2: one launch per conv, default)")
+    ap.add_argument("--tune", type=int, nargs="*", default=None, metavar="KNOB VALUE",
+                    help="experiment knobs: pairs for nfk_tune(knob, value) (include/nfk.h NFK_TUNE_*)")
+    ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_step2d_grads.bwd_mode of the student "
+                                                                 "(1 separate launches, 3 one launch per conv, 4 / default fused)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "
@@ -292,10 +295,9 @@ def main():
     from nf_distillation_amd import capi
     from param_util import synthetic_images
 
-    if args.tuning is not None:
-        capi.lib().nfk_set_tuning(args.tuning)
-    if args.bwd_mode is not None:
-        capi.lib().nfk_set_bwd_mode(args.bwd_mode)
+    tune = args.tune or []
+    for knob, value in zip(tune[0::2], tune[1::2]):
+        capi.lib().nfk_tune(knob, value)
 
     # synthetic data, resident in HBM before the timed region; a few distinct batches, cycled
     nb = 4

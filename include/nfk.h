@@ -78,9 +78,26 @@ typedef struct nfk_step2d {
 typedef struct nfk_step2d_grads {   /* per-call pointers of a step backward; the gradients all accumulate (+=) */
   float *g_w1, *g_b1, *g_l1, *g_w2, *g_b2, *g_l2, *g_w3, *g_bias3, *g_l3;
   float *mix_part;                  /* [nfk_chanmix_blocks(M, C)][C*C + C], consumed by nfk_prep_bwd */
-  const void *relu_masks;           /* what nfk_step2d_fwd_fused left in `masksave` for this step, or NULL (the fused
-                                     * step backward needs them; without, the step runs the per-conv launches) */
+  const void *relu_masks;           /* what nfk_step2d_fwd_fused left in `masksave` for this step (ReLU masks, then conv1's
+                                     * im2col rows), or NULL (the fused step backward needs them; without, the step runs
+                                     * the per-conv launches) */
+  int32_t bwd_mode, pad_;           /* NFK_BWD_*: how the bf16 backward of the coupling net is launched */
+  struct nfk_aux *aux;              /* optional auxiliary stream for the weight-gradient GEMMs (nfk_aux_create), or NULL */
 } nfk_step2d_grads;
+/* bf16 backward of a step's coupling net:
+ *   NFK_BWD_SEPARATE   every dgrad / weight-gradient GEMM its own launch (weight gradients on `aux` if one is given)
+ *   NFK_BWD_DUAL_SMALL a conv's dgrad + weight gradient as ONE launch for steps of at most 4096 pixels
+ *   NFK_BWD_DUAL       ... for every step
+ *   NFK_BWD_FUSED      (= NFK_BWD_DEFAULT) as DUAL, and where the geometry of nfk_step2d_fwd_fused applies and relu_masks is
+ *                      given the whole dgrad chain is ONE launch that keeps the 512-wide gradients in LDS
+ *                      (csrc/nfk_fusedb.hip), followed by ONE launch for the step's three weight-gradient GEMMs.
+ * The DUAL / FUSED launches ignore `aux`. */
+enum { NFK_BWD_DEFAULT = 0, NFK_BWD_SEPARATE = 1, NFK_BWD_DUAL_SMALL = 2, NFK_BWD_DUAL = 3, NFK_BWD_FUSED = 4 };
+/* An auxiliary stream plus the events that fork work to it and join it: created once per engine (two engines on two
+ * threads share nothing), passed per call in nfk_step2d_grads.aux.  `stream` must outlive the handle. */
+typedef struct nfk_aux nfk_aux;
+nfk_aux *nfk_aux_create(void *stream);
+void nfk_aux_destroy(nfk_aux *aux);
 
 /* Split2d (models/layers.py:293-313): Conv2dZeros(C/2 -> C) prior on the dropped half. */
 typedef struct nfk_split2d {
@@ -93,7 +110,11 @@ typedef struct nfk_split2d {
  * (models/flows.py:37-52, 142-202 with is_1d).  W[l]/b[l] are the nn.Linear weights [out][in] / biases of
  * block.{0,2,4,6,8,10}; Wf/cf/Wi/ci/dld come from nfk_prep. */
 typedef struct nfk_tab_step {
-  int32_t B, d, hid, ncond, additive, pad_;
+  int32_t B, d, hid, ncond, additive;
+  int32_t made;   /* 1: MADE / MAF block instead of a coupling (north_star's "MAF MADE blocks"; no reference code exists:
+                   * SURVEY.md section 0 F1, parity unpinned): W[0] is [hid][d + ncond], W[5] is [2 d][hid], both already
+                   * multiplied with the autoregressive masks by the caller; u_i = (y_i - mu_i) exp(-alpha_i) on every feature,
+                   * log|det| = -sum alpha_i; the inverse runs d passes of the MLP.  0: the reference's coupling step */
   const float *W[6];
   const float *b[6];
   const float *Wf, *cf, *Wi, *ci, *dld;
@@ -196,13 +217,12 @@ int nfk_step2d_inv(const nfk_step2d *s, const float *y, int ldy, const float *ld
 int nfk_step2d_bwd(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
                    const float *h1, const float *h2, const float *hsave, const float *g_out,
                    const float *g_ext, const float *g_ld, float *g_x, float *ws, void *stream);
-/* Same, for a caller that runs many steps back to back with an auxiliary stream set (nfk_set_aux_stream): the three
- * gradient tensors the weight-gradient GEMMs read are placed in `ga` (nfk_step2d_bwd_ga_floats floats, a buffer of its
- * own for every step until nfk_aux_join) and their split slabs in `wslab` (nfk_step2d_bwd_wslab_floats floats, may be
- * shared by all steps: only the auxiliary stream touches it), so that the auxiliary stream is NOT joined inside the
- * call and the dgrad chain of the next step starts at once.  nfk_aux_join makes `stream` wait for everything queued on
- * the auxiliary stream; the weight gradients are complete only after it.  Without an auxiliary stream (or with NULL
- * ga / wslab) this is nfk_step2d_bwd. */
+/* Same, for a caller that runs many steps back to back with an auxiliary stream (g->aux): the three gradient tensors the
+ * weight-gradient GEMMs read are placed in `ga` (nfk_step2d_bwd_ga_floats floats, a buffer of its own for every step until
+ * nfk_aux_join) and their split slabs in `wslab` (nfk_step2d_bwd_wslab_floats floats, may be shared by all steps: only the
+ * auxiliary stream touches it), so that the auxiliary stream is NOT joined inside the call and the dgrad chain of the next
+ * step starts at once.  nfk_aux_join makes `stream` wait for everything queued on the auxiliary stream; the weight
+ * gradients are complete only after it.  Without an auxiliary stream (or with NULL ga / wslab) this is nfk_step2d_bwd. */
 int nfk_step2d_bwd_deferred(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
                             const float *h1, const float *h2, const float *hsave, const float *g_out,
                             const float *g_ext, const float *g_ld, float *g_x, float *ws, float *ga, float *wslab,
@@ -229,20 +249,16 @@ int nfk_step2d_bwd_chain(const nfk_step2d *s, const nfk_step2d_grads *g, const f
                          const nfk_step2d_next *next, int *next_rows, void *stream);
 size_t nfk_step2d_bwd_ga_floats(const nfk_step2d *s);
 size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d *s);
-int nfk_aux_join(void *stream);
-/* bf16 backward: run a conv's dgrad GEMM and its weight-gradient GEMM as ONE launch (no second stream, no fork/join
- * edges in a captured graph).  0 = never, 1 = for steps of at most 4096 pixels (the small launches of the deep levels),
- * 2 = always.  3 (default) = as 2, and where the geometry of nfk_step2d_fwd_fused applies the whole dgrad chain of the
- * step (dgrad3 -> ReLU/ActNorm backward -> dgrad2 -> ... -> dgrad1) is ONE launch that keeps the 512-wide gradients in LDS
- * (csrc/nfk_fusedb.hip), followed by ONE launch for the step's three weight-gradient GEMMs.  Steps that use 1-3 ignore
- * the auxiliary stream. */
-void nfk_set_bwd_mode(int mode);
-/* 1 if nfk_step2d_bwd* would run this step through the fused backward (needs s->wg1..3 and relu_masks), else 0 */
+int nfk_aux_join(nfk_aux *aux, void *stream);
+/* 1 if nfk_step2d_bwd* (bwd_mode NFK_BWD_FUSED / DEFAULT) would run this step through the fused backward (needs s->wg1..3
+ * and relu_masks), else 0 */
 int nfk_step2d_fused_bwd_ok(const nfk_step2d *s);
 size_t nfk_step2d_mask_bytes(const nfk_step2d *s);   /* size of nfk_step2d_fwd_fused's masksave */
+/* diagnostic: leave parts of the fused backward's weight-gradient launch out, to time the others (bit 0: ActNorm sums,
+ * 1: conv2, 2: conv3, 3: conv1); gradients are then wrong.  0 = off */
+void nfk_debug_triple_parts(int skip_mask);
 /* diagnostic: device buffer [workgroups][16] of shader-clock stamps per phase of the fused backward (NULL = off) */
 void nfk_fused_bwd_set_stamps(void *buf);
-void *nfk_get_aux_stream(void);
 /* Fused forward of one FlowStep in ONE launch (bf16 mode, 64-pixel row tiles; see csrc/nfk_fused2.hip).
  * nfk_step2d_fused_tiles: 0 if this step's geometry is not supported (use nfk_step2d_fwd), else the number of
  * log-det partial slots per sample.  zsave/h1save/h2save/hsave as in nfk_step2d_fwd (NULL when no backward
@@ -367,19 +383,25 @@ enum { NFK_PROF_CONV_WIDE128 = 0, NFK_PROF_CONV_WIDE64 = 1, NFK_PROF_CONV_NARROW
        /* nfk_step2d_fwd_fused by conv3 width (one template instance each for Glow's shapes: CIFAR levels 1 / 2 / 3):
         * flops of the three convs, bytes = x + z + weights (+ what a training forward saves) */
        NFK_PROF_FUSED_STEP = 5, NFK_PROF_FUSED_STEP_NT2 = 6, NFK_PROF_FUSED_STEP_NT3 = 7,
-       /* dgrad + wgrad of one conv in one launch (nfk_set_bwd_mode): 9 classes = conv (block.4, .2, .0) x size bucket
+       /* dgrad + wgrad of one conv in one launch (NFK_BWD_DUAL): 9 classes = conv (block.4, .2, .0) x size bucket
         * (M >= 8192, >= 2048, smaller: CIFAR levels 1 / 2 / 3 at B = 64), one template instance each for Glow's shapes */
        NFK_PROF_DUAL_BWD = 8,
-       /* fused step backward (nfk_set_bwd_mode(3), default in bf16 mode where the geometry allows): the dgrad chain of a
+       /* fused step backward (NFK_BWD_FUSED, default in bf16 mode where the geometry allows): the dgrad chain of a
         * FlowStep in one launch (3 classes by size bucket as above) and its three weight-gradient GEMMs in one launch */
        NFK_PROF_FUSED_BWD = 17, NFK_PROF_TRIPLE_WGRAD = 20,
        NFK_PROF_CLASSES = 23 };
 void nfk_profile_begin(void);
-/* Optional: a second stream on which nfk_step2d_bwd runs its weight-gradient GEMMs concurrently with the
- * dgrad chain (forked/joined with events inside the call; NULL = everything on the caller's stream). */
-void nfk_set_aux_stream(void *stream);
-/* experiment knob for tools/gemm_bench.py: selects an alternative tile configuration (0 = default) */
-void nfk_set_tuning(int v);
+/* Process-wide experiment knobs of the GEMM launch heuristics (tools/, A/B tests of kernel variants): not part of the data
+ * path's interface, defaults are what production uses. */
+enum { NFK_TUNE_F32_TILES = 0,               /* fp32 wide conv: 0 default, 1..5 alternative tile configurations */
+       NFK_TUNE_BF16_BIG_TILE_MIN_K64 = 1,   /* bf16 128x128 tiles only for K > 64 * value */
+       NFK_TUNE_WGRAD_MAX_SPLITS = 2,        /* cap of the weight-gradient split-K */
+       NFK_TUNE_WGRAD_TARGET_WGS = 3,        /* workgroups a weight-gradient launch aims at */
+       NFK_TUNE_WGRAD_WIDE_MAX_SPLITS = 4,   /* cap for the 512x512 weight gradient */
+       NFK_TUNE_NARROW_HALO_DGRAD = 5,       /* 1/0: conv1's dgrad through the halo-tile kernel / the split-K GEMM */
+       NFK_TUNE_WGRAD_HALO = 6,              /* 1/0: conv3's weight gradient through the halo-tile kernel / the generic one */
+       NFK_TUNE_WGRAD_HALO_MAX_SPLITS = 7 };
+void nfk_tune(int knob, int value);
 void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
 
 /* same, with the step count kept on the device (*step_dev = completed steps, incremented here), so the

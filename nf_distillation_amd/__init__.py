@@ -6,7 +6,7 @@ Drop-in names (the reference's ``models/__init__.py:1-3``)::
     from nf_distillation_amd import (create_glow_model, inherit_permutation_matrix, FlowStep,
                                      gaussian_sample, SqueezeLayer)
 """
-from .modules import (ActNorm1d, ActNorm2d, Conv2d, Conv2dZeros, FlowNet, FlowNetGetAllOutputs, FlowStep, Glow,
+from .modules import (ActNorm1d, ActNorm2d, Conv2d, Conv2dZeros, FlowNet, FlowNetGetAllOutputs, FlowStep, Glow, MADEStep,
                       GlowGetAllOutputs, InvertibleConv1x1, LinearZeros, Permute2d, Split2d, SqueezeLayer,
                       create_glow_model, gaussian_sample, inherit_permutation_matrix, split_feature)
 from .checkpoint import load_checkpoint

@@ -53,7 +53,7 @@ class Step2d(C.Structure):
 class Step2dGrads(C.Structure):
     _fields_ = [("g_w1", c_fp), ("g_b1", c_fp), ("g_l1", c_fp), ("g_w2", c_fp), ("g_b2", c_fp),
                 ("g_l2", c_fp), ("g_w3", c_fp), ("g_bias3", c_fp), ("g_l3", c_fp), ("mix_part", c_fp),
-                ("relu_masks", c_fp)]
+                ("relu_masks", c_fp), ("bwd_mode", C.c_int32), ("pad_", C.c_int32), ("aux", c_fp)]
 
 
 class FusedRun(C.Structure):
@@ -75,7 +75,7 @@ class Split2d(C.Structure):
 
 class TabStepC(C.Structure):
     _fields_ = [("B", C.c_int32), ("d", C.c_int32), ("hid", C.c_int32), ("ncond", C.c_int32),
-                ("additive", C.c_int32), ("pad_", C.c_int32),
+                ("additive", C.c_int32), ("made", C.c_int32),
                 ("W", c_fp * 6), ("b", c_fp * 6),
                 ("Wf", c_fp), ("cf", c_fp), ("Wi", c_fp), ("ci", c_fp), ("dld", c_fp)]
 
@@ -85,6 +85,11 @@ class TabGrads(C.Structure):
 
 
 KD_MAX_PAIRS = 16   # NFK_KD_MAX_PAIRS
+# nfk_step2d_grads.bwd_mode (include/nfk.h)
+BWD_DEFAULT, BWD_SEPARATE, BWD_DUAL_SMALL, BWD_DUAL, BWD_FUSED = 0, 1, 2, 3, 4
+# nfk_tune knobs
+(TUNE_F32_TILES, TUNE_BF16_BIG_TILE_MIN_K64, TUNE_WGRAD_MAX_SPLITS, TUNE_WGRAD_TARGET_WGS, TUNE_WGRAD_WIDE_MAX_SPLITS,
+ TUNE_NARROW_HALO_DGRAD, TUNE_WGRAD_HALO, TUNE_WGRAD_HALO_MAX_SPLITS) = range(8)
 
 
 class KdPairs(C.Structure):
@@ -107,8 +112,9 @@ i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long
 _PROTOS = {
     "nfk_version": (C.c_char_p, []),
     "nfk_profile_begin": (None, []),
-    "nfk_set_tuning": (None, [i32]),
-    "nfk_set_aux_stream": (None, [vp]),
+    "nfk_tune": (None, [i32, i32]),
+    "nfk_aux_create": (vp, [vp]),
+    "nfk_aux_destroy": (None, [vp]),
     "nfk_profile_end": (None, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
     "nfk_padded_k": (i32, [i32]),
@@ -144,11 +150,10 @@ _PROTOS = {
                                    vp, vp, vp, vp, i32, C.POINTER(Step2dNext), C.POINTER(i32), vp]),
     "nfk_step2d_bwd_ga_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_bwd_wslab_floats": (u64, [C.POINTER(Step2d)]),
-    "nfk_aux_join": (i32, [vp]),
-    "nfk_set_bwd_mode": (None, [i32]),
-    "nfk_get_aux_stream": (vp, []),
+    "nfk_aux_join": (i32, [vp, vp]),
     "nfk_step2d_fused_bwd_ok": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_bwd_set_stamps": (None, [vp]),
+    "nfk_debug_triple_parts": (None, [i32]),
     "nfk_step2d_mask_bytes": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_fused_tiles": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_set_stamps": (None, [vp]),

@@ -77,33 +77,51 @@ int splitk_of(int bf16, int M, int N, int K) {
 }
 }  // namespace
 
-// Optional auxiliary stream: when set, the weight-gradient GEMMs of a step's backward run on it,
-// concurrently with the dgrad chain on the caller's stream (fork/join with events; capturable).
-static hipStream_t g_aux = nullptr;
-static int g_bwd_mode = 3;
+// Optional auxiliary stream (nfk_aux_create): the weight-gradient GEMMs of a step's backward run on it, concurrently with
+// the dgrad chain on the caller's stream (fork/join with events; capturable).  The handle travels in nfk_step2d_grads, so
+// two engines on two threads / streams do not share any state.
+struct nfk_aux {
+  hipStream_t stream;
+  hipEvent_t ev[4];
+  bool forked;   // work was sent to the auxiliary stream since the last join
+};
 static unsigned long long* g_bwd_stamps = nullptr;   // diagnostic (nfk_fused_bwd_set_stamps)
-static hipEvent_t g_ev[4];
-static bool g_ev_ready = false;
-static bool g_aux_forked = false;   // work was sent to the auxiliary stream since the last join
-static void fork_to_aux(hipStream_t main_st, int i) {
-  g_aux_forked = true;
-  (void)hipEventRecord(g_ev[i], main_st);
-  (void)hipStreamWaitEvent(g_aux, g_ev[i], 0);
+static void fork_to_aux(nfk_aux* ax, hipStream_t main_st, int i) {
+  ax->forked = true;
+  (void)hipEventRecord(ax->ev[i], main_st);
+  (void)hipStreamWaitEvent(ax->stream, ax->ev[i], 0);
 }
+// nfk_step2d_grads.bwd_mode -> 0 separate launches, 1 dual launches for small steps, 2 dual launches, 3 fused backward
+static inline int bwd_mode_of(const nfk_step2d_grads* g) { return g->bwd_mode == NFK_BWD_DEFAULT ? 3 : g->bwd_mode - 1; }
 
 extern "C" {
 
-void nfk_set_aux_stream(void* stream) {
-  g_aux = reinterpret_cast<hipStream_t>(stream);
-  if (g_aux && !g_ev_ready) {
-    for (auto& e : g_ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    g_ev_ready = true;
-  }
+nfk_aux* nfk_aux_create(void* stream) {
+  if (!stream) return nullptr;
+  nfk_aux* ax = new nfk_aux{};
+  ax->stream = reinterpret_cast<hipStream_t>(stream);
+  for (auto& e : ax->ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ax; return nullptr; }
+  return ax;
+}
+void nfk_aux_destroy(nfk_aux* ax) {
+  if (!ax) return;
+  for (auto& e : ax->ev) (void)hipEventDestroy(e);
+  delete ax;
 }
 
-void nfk_set_tuning(int v) {
-  if (v >= 100) set_tuning_bf16(v - 100);   // 100 + n: bf16 128x128 tiles only for K > 64 n  (0: whenever they fill the chip)
-  else set_tuning(v);
+void nfk_tune(int knob, int value) {
+  switch (knob) {
+    case NFK_TUNE_F32_TILES: set_tuning(value); break;
+    case NFK_TUNE_BF16_BIG_TILE_MIN_K64: set_tuning_bf16(value); break;
+    case NFK_TUNE_WGRAD_MAX_SPLITS: set_tuning_bf16(100 + value); break;
+    case NFK_TUNE_WGRAD_TARGET_WGS: set_tuning_bf16(900 + value); break;
+    case NFK_TUNE_WGRAD_WIDE_MAX_SPLITS: set_tuning_bf16(2000 + value); break;
+    case NFK_TUNE_NARROW_HALO_DGRAD: set_tuning_bf16(2900 + (value & 1)); break;
+    case NFK_TUNE_WGRAD_HALO: set_tuning_bf16(2910 + (value & 1)); break;
+    case NFK_TUNE_WGRAD_HALO_MAX_SPLITS: set_tuning_bf16(3000 + value); break;
+    default: break;
+  }
 }
 void nfk_profile_begin(void) { prof_begin(); }
 void nfk_profile_end(double* ms, long long* launches, double* flops, double* bytes) {
@@ -276,7 +294,9 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   const StepBwdWs L = step_bwd_layout(s);
   float *ga3 = ws + L.ga3, *gz = ws + L.gz, *ga2 = ws + L.ga2, *ga1 = ws + L.ga1, *d1 = ws + L.d1slab;
   float *col2 = ws + L.col2, *col1 = ws + L.col1, *tail = ws + L.tail, *wslab = ws + L.wslab;
-  const bool deferred = ga != nullptr && wslab_ext != nullptr && g_aux != nullptr && g_aux != st;
+  nfk_aux* const ax = g->aux;
+  const int bwd_mode = bwd_mode_of(g);
+  const bool deferred = ga != nullptr && wslab_ext != nullptr && ax != nullptr && ax->stream != st;
   if (deferred) {   // the three tensors the weight-gradient GEMMs read live in this step's own buffer
     ga3 = ga;
     ga2 = ga3 + align4((size_t)M * Cout);
@@ -292,12 +312,12 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   // Each conv's weight gradient (slabs -> finalize) and dgrad read the same output gradient and are independent.
   // bf16 "dual" mode runs the two GEMMs as ONE launch on the caller's stream; otherwise the weight gradient goes to
   // the auxiliary stream (if one is set), forked here and joined at the end of the call / by nfk_aux_join.
-  const bool dual = bf && (g_bwd_mode >= 2 || (g_bwd_mode == 1 && M <= 4096));
+  const bool dual = bf && (bwd_mode >= 2 || (bwd_mode == 1 && M <= 4096));
   // fused backward: needs the ReLU masks the fused forward leaves (g->relu_masks) and a supported geometry
-  const int fgrid = (bf && g_bwd_mode == 3 && g->relu_masks) ? fusedb_grid(*s) : 0;
+  const int fgrid = (bf && bwd_mode == 3 && g->relu_masks) ? fusedb_grid(*s) : 0;
   hipStream_t ws_st = st;  // stream of the wgrad GEMMs
-  const bool use_aux = !dual && g_aux && g_aux != st;
-  if (use_aux) ws_st = g_aux;
+  const bool use_aux = !dual && ax && ax->stream != st;
+  if (use_aux) ws_st = ax->stream;
   int fork_i = 0, conv_i = 0;
   StepTailArgs tail_f{};   // slab reductions deferred to the one launch at the end of the step (dual mode)
   auto conv_bwd = [&](const ConvGemmArgs& dg, const WgradArgs& wg, int Sw, int Co, int Ci, int taps, float* gw) -> int {
@@ -311,7 +331,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
       }
       if (rc != NFK_ERR_ARG) return rc;   // NFK_ERR_ARG: this pair of tile shapes is not instantiated
     }
-    if (use_aux) fork_to_aux(st, fork_i++);
+    if (use_aux) fork_to_aux(ax, st, fork_i++);
     NFK_TRY(bf ? wgrad_gemm_bf16(wg, Sw, ws_st) : wgrad_gemm(wg, Sw, ws_st));
     NFK_TRY(wgrad_finalize(wg.out, Sw, wg.slab_stride, Co, Ci, taps, gw, ws_st));
     return run_conv(bf, dg, st);
@@ -414,9 +434,9 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
     NFK_TRY(launch_chanmix(m, st));
   }
   if (ws_st != st && !deferred) {  // join: this step's workspace and weight grads are complete when the call's stream moves on
-    (void)hipEventRecord(g_ev[3], ws_st);
-    (void)hipStreamWaitEvent(st, g_ev[3], 0);
-    g_aux_forked = false;
+    (void)hipEventRecord(ax->ev[3], ws_st);
+    (void)hipStreamWaitEvent(st, ax->ev[3], 0);
+    ax->forked = false;
   }
   return NFK_OK;
 }
@@ -447,21 +467,21 @@ size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d* s) {
   const StepBwdWs L = step_bwd_layout(s);
   return L.total - L.wslab;
 }
-void* nfk_get_aux_stream(void) { return g_aux; }
+void nfk_debug_triple_parts(int skip_mask) { triple_wgrad_debug_skip(skip_mask); }
 void nfk_fused_bwd_set_stamps(void* buf) { g_bwd_stamps = reinterpret_cast<unsigned long long*>(buf); }
-int nfk_step2d_fused_bwd_ok(const nfk_step2d* s) { return (s->bf16 && g_bwd_mode == 3 && fusedb_grid(*s) > 0) ? 1 : 0; }
+int nfk_step2d_fused_bwd_ok(const nfk_step2d* s) { return (s->bf16 && fusedb_grid(*s) > 0) ? 1 : 0; }
 size_t nfk_step2d_mask_bytes(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;
   return 2 * M * (s->hidden / 8) + M * fused2_k1p(*s) * 2;   // ReLU masks of h1 / h2, then conv1's im2col rows (bf16)
 }
-void nfk_set_bwd_mode(int mode) { g_bwd_mode = mode; }
-int nfk_aux_join(void* stream) {
+int nfk_aux_join(nfk_aux* ax, void* stream) {
   hipStream_t st = S_(stream);
-  if (g_aux && g_aux != st && g_aux_forked) {   // nothing to wait for otherwise (and, while `st` is being captured,
-    (void)hipEventRecord(g_ev[3], g_aux);       // an event of a stream outside the capture must not be waited on)
-    (void)hipStreamWaitEvent(st, g_ev[3], 0);
+  if (!ax) return NFK_OK;
+  if (ax->stream != st && ax->forked) {              // nothing to wait for otherwise (and, while `st` is being captured,
+    (void)hipEventRecord(ax->ev[3], ax->stream);     // an event of a stream outside the capture must not be waited on)
+    (void)hipStreamWaitEvent(st, ax->ev[3], 0);
   }
-  g_aux_forked = false;
+  ax->forked = false;
   return NFK_OK;
 }
 

@@ -18,10 +18,14 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int BKH = 64;                 // bf16 elements per k-chunk
-static int g_narrow_halo = 1;            // conv1 dgrad through the halo-tile kernel (nfk_set_tuning(3000 / 3001))
-static int g_wgrad_wide_max_splits = 32;   // 512x512: 1 MiB per split; 32 = an even 8 chunks per split at CIFAR level 1 (+2.6 % over 48)
-static int g_wgrad_target_wgs = 768, g_wgrad_max_splits = 64;   // nfk_set_tuning(200 + cap) / (1000 + target)
-static int g_big_tile_min_k = 256;      // see big_tiles(); nfk_set_tuning(100 + v) sets it to v*64 (experiments)
+static int g_narrow_halo = 1;            // conv1 dgrad through the halo-tile kernel (nfk_tune NFK_TUNE_NARROW_HALO_DGRAD)
+// Split caps of the weight-gradient GEMMs.  With the fused backward all three GEMMs of a step share one launch, every
+// workgroup is a short latency-bound pipeline (load a 64-pixel chunk, 32 MFMAs, next chunk) and every split leaves a slab
+// the step tail reads back: 16 splits (16 chunks per workgroup at CIFAR level 1, 16 MiB of conv2 slabs instead of 32)
+// measured +2.7 % step throughput over 32 / 64.
+static int g_wgrad_wide_max_splits = 16;   // 512x512: 1 MiB per split
+static int g_wgrad_target_wgs = 768, g_wgrad_max_splits = 16;   // nfk_tune NFK_TUNE_WGRAD_MAX_SPLITS / _TARGET_WGS
+static int g_big_tile_min_k = 256;      // see big_tiles(); nfk_tune NFK_TUNE_BF16_BIG_TILE_MIN_K64 sets it to v*64 (experiments)
 constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
@@ -754,7 +758,7 @@ static bool wgrad_halo_usable(int M, int NI, int Cq, int taps, int W) {
   return g_wgrad_halo && taps == 9 && NI >= 1 && NI <= 16 && Cq >= 128 && Cq % 128 == 0 && W >= 1 && W <= 64 && M >= 64 &&
          M % 64 == 0 && wh_lds_bytes(W) <= 64 * 1024;
 }
-static int g_wgrad_halo_max_splits = 32;   // nfk_set_tuning(3100 + n)
+static int g_wgrad_halo_max_splits = 32;   // nfk_tune NFK_TUNE_WGRAD_HALO_MAX_SPLITS
 static int wgrad_halo_splits(int M) {
   const int nchunks = M / 64;
   return nchunks < g_wgrad_halo_max_splits ? nchunks : g_wgrad_halo_max_splits;
@@ -978,6 +982,9 @@ __global__ void __launch_bounds__(256) triple_wgrad_bf16_kernel(WgradArgs w2, in
   wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1);
 }
 
+static int g_triple_skip = 0;
+void triple_wgrad_debug_skip(int mask) { g_triple_skip = mask; }
+
 template <int V3>
 static int launch_triple(const WgradArgs& w3, int S3, const WgradArgs& w2, int S2, const WgradArgs& w1, int S1,
                          const ActnormSumArgs& an, hipStream_t st, double alg_nj) {
@@ -1003,8 +1010,14 @@ static int launch_triple(const WgradArgs& w3, int S3, const WgradArgs& w2, int S
   prof_scope_begin(cls, 2.0 * w2.M * nj,
                    w2.M * (2.0 * w2.NI + 2.0 * w2.Cq + 2.0 * w1.NI + 4.0 * w1.Cq + 4.0 * w3.NI + 2.0 * w3.Cq) +
                        4.0 * (S2 * (double)w2.NI * w2.J + S1 * (double)w1.NI * w1.J + S3 * (double)w3.NI * w3.J), st);
-  hipLaunchKernelGGL((triple_wgrad_bf16_kernel<V3>), dim3(nb2 * S2 + nb1 * S1 + n3 + an.nparts), dim3(256), lds, st, w2, nb2,
-                     S2, w1, nb1, S1, w3, nb3, S3, n3, an);
+  // diagnostic (nfk_debug_triple_parts): leave parts of the launch out to time the others (bit 0: ActNorm sums, 1: conv2,
+  // 2: conv3, 3: conv1); results are then wrong
+  ActnormSumArgs anx = an;
+  if (g_triple_skip & 1) anx.nparts = 0;
+  const int S2x = (g_triple_skip & 2) ? 0 : S2, n3x = (g_triple_skip & 4) ? 0 : n3, S1x = (g_triple_skip & 8) ? 0 : S1;
+  if (nb2 * S2x + nb1 * S1x + n3x + anx.nparts == 0) return NFK_OK;
+  hipLaunchKernelGGL((triple_wgrad_bf16_kernel<V3>), dim3(nb2 * S2x + nb1 * S1x + n3x + anx.nparts), dim3(256), lds, st, w2,
+                     nb2, S2x, w1, nb1, S1x, w3, nb3, S3, n3x, anx);
   prof_scope_end(cls, st);
   NFK_LAUNCH_CHECK();
   return NFK_OK;

@@ -149,6 +149,7 @@ int fused2_k1p(const nfk_step2d& s);     // row length of the im2col rows the fu
 // the three weight-gradient GEMMs of a step (block.4, .2, .0) in ONE launch; NFK_ERR_ARG: shapes not instantiated
 int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an, hipStream_t st,
                       double alg_nj = 0.0);
+void triple_wgrad_debug_skip(int mask);
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 int fused2_launch(const FusedCall& c, hipStream_t st);
 size_t fused2_ws_floats(const nfk_step2d& s);

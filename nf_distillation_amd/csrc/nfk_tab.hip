@@ -22,11 +22,17 @@ __host__ __device__ static inline int tab_rows(int hid, int d) {
   while (tr > 1 && tr * g4 > 256) tr >>= 1;
   return tr;
 }
+// MADE mode (nfk_tab_step.made): the block is autoregressive instead of a coupling -- the MLP (whose weights the caller has
+// multiplied with the autoregressive masks) sees ALL d features and returns (mu_i, alpha_i) for every feature, interleaved
+// like the coupling's (shift, scale);  u_i = (y_i - mu_i) exp(-alpha_i),  log|det| = -sum_i alpha_i  (MAF, Papamakarios et
+// al. 2017, eq. 3-5; the reference repository contains no such code: SURVEY.md section 0 F1).
+__host__ __device__ static inline int tab_nfeat(const TabStep& s) { return s.made ? s.d : s.d / 2; }   // features fed to the MLP
 __host__ __device__ static inline int tab_nout(const TabStep& s) {
+  if (s.made) return 2 * s.d;
   const int C2 = s.d - s.d / 2;
   return s.additive ? C2 : 2 * C2;
 }
-__host__ __device__ static inline int tab_nin0(const TabStep& s) { return s.d / 2 + s.ncond; }
+__host__ __device__ static inline int tab_nin0(const TabStep& s) { return tab_nfeat(s) + s.ncond; }
 __host__ __device__ static inline int tab_layer_in(const TabStep& s, int l) { return l == 0 ? tab_nin0(s) : s.hid; }
 __host__ __device__ static inline int tab_layer_out(const TabStep& s, int l) { return l == 5 ? tab_nout(s) : s.hid; }
 __host__ __device__ static inline int tab_param_floats(const TabStep& s) {
@@ -59,7 +65,15 @@ __host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, 
   size_t oH[5];
   for (int k = 0; k < 5; ++k) oH[k] = take((size_t)TR * HS);
   size_t oO = take((size_t)TR * OS);
-  size_t oW = take((size_t)mx * pad4(mx));
+  // staged weights of one dense layer [inputs][pad4(outputs)]: the largest of the layers' shapes (and their transposes in
+  // the backward), not mx x mx -- with 2 d outputs (MADE, d = 63) that alone would be 64 KiB
+  size_t wmax = (size_t)d * pad4(d);
+  {
+    const size_t c[5] = {(size_t)nin0 * pad4(hid), (size_t)hid * pad4(hid), (size_t)hid * pad4(nout),
+                         (size_t)hid * pad4(nin0), (size_t)nout * pad4(hid)};
+    for (size_t v : c) if (v > wmax) wmax = v;
+  }
+  size_t oW = take(wmax);
   size_t oGA = 0, oGB = 0, oGY = 0, oP = 0, oPM = 0;
   if (bwd) {
     oGA = take((size_t)TR * GS); oGB = take((size_t)TR * GS); oGY = take((size_t)TR * XS);
@@ -115,18 +129,18 @@ __device__ void tab_dense(const float* in, int ldi, int nin, const float* __rest
 
 // Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
 __device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0) {
-  const int d = s.d, Ch = d / 2, TR = L.TR;
+  const int d = s.d, TR = L.TR;
   for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
     const int p = idx / d, c = idx - p * d, m = row0 + p;
     L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
   }
   tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
-  const int nin0 = tab_nin0(s);
+  const int nin0 = tab_nin0(s), nf = tab_nfeat(s);
   for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
     const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
     float v;
-    if (c < Ch) v = L.Y[p * L.XS + c];
-    else v = m < s.B ? cond[(long)m * s.ncond + (c - Ch)] : 0.f;
+    if (c < nf) v = L.Y[p * L.XS + c];
+    else v = m < s.B ? cond[(long)m * s.ncond + (c - nf)] : 0.f;
     L.IN0[p * L.IS + c] = v;
   }
   const float* in = L.IN0;
@@ -150,6 +164,26 @@ __global__ void __launch_bounds__(256) tab_fwd_kernel(TabStep s, const float* __
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * TR;
     tab_forward_tile(s, L, x, cond, row0);
+    if (s.made) {   // u = (y - mu) exp(-alpha) on every feature; log-det terms -alpha into X
+      for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+        const int p = idx / d, j = idx - p * d, m = row0 + p;
+        const float mu = L.O[p * L.OS + 2 * j], al = L.O[p * L.OS + 2 * j + 1];
+        L.X[p * L.XS + j] = -al;
+        if (m < s.B) zout[(long)m * d + j] = (L.Y[p * L.XS + j] - mu) * expf(-al);
+      }
+      __syncthreads();
+      if (ld_out)
+        for (int p = threadIdx.x; p < TR; p += blockDim.x) {
+          const int m = row0 + p;
+          if (m < s.B) {
+            float t = 0.f;
+            for (int j = 0; j < d; ++j) t += L.X[p * L.XS + j];
+            ld_out[m] = ld_in[m] + s.dld[0] + t;
+          }
+        }
+      __syncthreads();
+      continue;
+    }
     // coupling tail; log-scale terms go to GA-less scratch: reuse X (no longer needed) as [TR][XS]
     for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
       const int p = idx / C2, j = idx - p * C2, m = row0 + p;
@@ -199,6 +233,49 @@ __global__ void __launch_bounds__(256) tab_inv_kernel(TabStep s, const float* __
       L.Y[p * L.XS + c] = m < s.B ? y[(long)m * d + c] : 0.f;
     }
     __syncthreads();
+    if (s.made) {
+      // autoregressive inverse: y_i = u_i exp(alpha_i) + mu_i with (mu_i, alpha_i) functions of y_<i only (the masks):
+      // d passes of the MLP over the tile, pass i fixes feature i.  U = the step output (kept in X), Y starts at zero
+      for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+        const int p = idx / d, c = idx - p * d;
+        L.X[p * L.XS + c] = L.Y[p * L.XS + c];
+        L.Y[p * L.XS + c] = 0.f;
+      }
+      __syncthreads();
+      for (int i = 0; i < d; ++i) {
+        for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+          const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+          L.IN0[p * L.IS + c] = c < d ? L.Y[p * L.XS + c] : (m < s.B ? cond[(long)m * s.ncond + (c - d)] : 0.f);
+        }
+        const float* in = L.IN0;
+        int ldi = L.IS;
+        for (int l = 0; l < 5; ++l) {
+          tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+          in = L.H[l];
+          ldi = L.HS;
+        }
+        tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+        for (int p = threadIdx.x; p < TR; p += blockDim.x)
+          L.Y[p * L.XS + i] = L.X[p * L.XS + i] * expf(L.O[p * L.OS + 2 * i + 1]) + L.O[p * L.OS + 2 * i];
+        __syncthreads();
+      }
+      // after the last pass every alpha_i in O is final (alpha_i depends on y_<i, all fixed by then)
+      if (ld_out)
+        for (int p = threadIdx.x; p < TR; p += blockDim.x) {
+          const int m = row0 + p;
+          if (m < s.B) {
+            float t = 0.f;
+            for (int j = 0; j < d; ++j) t += L.O[p * L.OS + 2 * j + 1];
+            ld_out[m] = ld_in[m] - s.dld[0] + t;   // forward added -sum alpha
+          }
+        }
+      tab_dense(L.Y, L.XS, d, s.Wi, s.ci, L.X, L.XS, d, 0, 0, L.Wl, TR);
+      for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+        const int p = idx / d, c = idx - p * d, m = row0 + p;
+        if (m < s.B) xout[(long)m * d + c] = L.X[p * L.XS + c];
+      }
+      continue;
+    }
     for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
       const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
       L.IN0[p * L.IS + c] = c < Ch ? L.Y[p * L.XS + c] : (m < s.B ? cond[(long)m * s.ncond + (c - Ch)] : 0.f);
@@ -298,6 +375,18 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
     const int row0 = tile * TR;
     tab_forward_tile(s, L, x, cond, row0);
     // ---- tail backward: grads wrt O (into GA) and wrt y2 (into GY second half)
+    if (s.made)   // u = (y - mu) e^-alpha, ld += -alpha:  g_mu = -g_u e^-alpha, g_alpha = -g_u u - g_ld, g_y (direct) = g_u e^-alpha
+      for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+        const int p = idx / d, j = idx - p * d, m = row0 + p;
+        const float gu = m < s.B ? gout[(long)m * d + j] : 0.f;
+        const float gl = (m < s.B && gld) ? gld[m] : 0.f;
+        const float mu = L.O[p * L.OS + 2 * j], al = L.O[p * L.OS + 2 * j + 1], e = expf(-al);
+        const float u = (L.Y[p * L.XS + j] - mu) * e;
+        L.GA[p * L.GS + 2 * j] = -gu * e;
+        L.GA[p * L.GS + 2 * j + 1] = m < s.B ? -gu * u - gl : 0.f;
+        L.GY[p * L.XS + j] = gu * e;
+      }
+    else
     for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
       const int p = idx / C2, j = idx - p * C2, m = row0 + p;
       const float g2 = m < s.B ? gout[(long)m * d + Ch + j] : 0.f;
@@ -316,11 +405,14 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
     }
     __syncthreads();
     const float* g = tab_mlp_backward(s, L);
-    // g = grad wrt IN0 = (z1 | cond)
+    // g = grad wrt IN0 = (z1 | cond)   (MADE: (y | cond), added to the direct term of the tail)
+    const int nf = tab_nfeat(s);
     for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
       const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
-      if (c < Ch) L.GY[p * L.XS + c] = g[p * L.GS + c] + (m < s.B ? gout[(long)m * d + c] : 0.f);
-      else if (gcond && m < s.B) gcond[(long)m * s.ncond + (c - Ch)] += g[p * L.GS + c];
+      if (c < nf) {
+        if (s.made) L.GY[p * L.XS + c] += g[p * L.GS + c];
+        else L.GY[p * L.XS + c] = g[p * L.GS + c] + (m < s.B ? gout[(long)m * d + c] : 0.f);
+      } else if (gcond && m < s.B) gcond[(long)m * s.ncond + (c - nf)] += g[p * L.GS + c];
     }
     __syncthreads();
     // ---- mix backward: gx = Wf^T gy ; partial (gWf, gcf)
@@ -535,7 +627,7 @@ int nfk_tab_inv_bwd(const nfk_tab_step* s, const nfk_tab_grads* g, const float* 
                     const float* g_x, const float* g_ld, float* g_y, float* g_cond, float* part, float* part_mix,
                     void* stream) {
   size_t lds;
-  if (tab_check(*s, true, &lds) != NFK_OK || !s->Wi) return NFK_ERR_ARG;
+  if (tab_check(*s, true, &lds) != NFK_OK || !s->Wi || s->made) return NFK_ERR_ARG;   // (no reverse pass with gradients for MADE)
   if (s->B == 0) return NFK_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_inv_bwd_kernel),

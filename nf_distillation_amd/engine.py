@@ -48,7 +48,7 @@ class FlowEngine:
         self.layers = layers
         self.state = None
         self.key = None
-        self.is_1d = any(isinstance(l, M.FlowStep) and l.is_1d for l in layers)
+        self.is_1d = any(isinstance(l, (M.FlowStep, M.MADEStep)) and l.is_1d for l in layers)
         self._params = None
         self._tensor_list = None
         self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
@@ -62,6 +62,8 @@ class FlowEngine:
         # all FlowSteps of a level in ONE launch where the pixel tiles are whole images (nfk_run2d_fwd_fused; bit-identical
         # to the per-step launches without hidden split).  "inference": only for passes that keep nothing (a frozen teacher)
         self.fused_runs = True
+        self.bwd_mode = capi.BWD_DEFAULT   # nfk_step2d_grads.bwd_mode: how the bf16 backward of a coupling net is launched
+        self.aux = None        # nfk_aux handle (training.enable_concurrency): auxiliary stream of the weight-gradient GEMMs
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -103,6 +105,9 @@ class FlowEngine:
     def mark_dirty(self):
         if self.state is not None:
             self.state["version"] = None
+            for r in self.state["recs"]:
+                if r.tab is not None:
+                    r.tab.mark_dirty()   # (MADE blocks: W * mask is rebuilt)
 
     # ------------------------------------------------------------------ build
     def _build(self, B, in_shape, device):
@@ -123,13 +128,13 @@ class FlowEngine:
             if isinstance(layer, M.SqueezeLayer):
                 r.kind, r.C, r.H, r.W = "squeeze", Cc, H, W  # INPUT dims
                 Cc, H, W = Cc * 4, H // 2, W // 2
-            elif isinstance(layer, M.FlowStep):
+            elif isinstance(layer, (M.FlowStep, M.MADEStep)):
                 if layer.in_channels != Cc:
                     raise ValueError(f"layer {i}: expected {layer.in_channels} channels, got {Cc}")
                 r.kind = "tab" if layer.is_1d else "step"
                 r.C, r.H, r.W, r.hid = Cc, H, W, layer.hidden_channels
                 r.additive = 1 if layer.flow_coupling == "additive" else 0
-                r.Cout = (Cc - Cc // 2) * (1 if r.additive else 2)
+                r.Cout = 2 * Cc if layer.flow_coupling == "made" else (Cc - Cc // 2) * (1 if r.additive else 2)
                 off = {}
                 o = prep_floats
                 for name, n in (("Wf", Cc * Cc), ("cf", Cc), ("Wi", Cc * Cc), ("ci", Cc), ("dld", 4),
@@ -509,9 +514,11 @@ class _DecodeFn(torch.autograd.Function):
                 if r.C > 74:
                     raise RuntimeError("reverse-pass gradients support at most 74 features per step")
                 d.part, d.nparts = r.tab.part_mix_inv.data_ptr(), r.tab.nblk
-                an, ic = r.mod.actnorm, r.mod.invconv
+                an, ic = r.mod.actnorm, getattr(r.mod, "invconv", None)
                 d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
-                if ic.LU_decomposed:
+                if ic is None:
+                    pass   # fixed permutation (MADE block): no parameters behind the mix
+                elif ic.LU_decomposed:
                     d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
                 else:
                     d.g_weight = ptr(ic.weight.grad)
@@ -755,9 +762,11 @@ class _EncodeFn(torch.autograd.Function):
                 d = PrepGrad()
                 if r.tab.part_mix is not None:
                     d.part, d.nparts = r.tab.part_mix.data_ptr(), r.tab.nblk
-                    an, ic = r.mod.actnorm, r.mod.invconv
+                    an, ic = r.mod.actnorm, getattr(r.mod, "invconv", None)
                     d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
-                    if ic.LU_decomposed:
+                    if ic is None:
+                        pass   # fixed permutation (MADE block): no parameters behind the mix
+                    elif ic.LU_decomposed:
                         d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
                     else:
                         d.g_weight = ptr(ic.weight.grad)
@@ -786,7 +795,7 @@ class _EncodeFn(torch.autograd.Function):
         # With an auxiliary stream (training.enable_concurrency) and no per-layer gradient hook, the weight-gradient
         # GEMMs of ALL steps form one chain on that stream, fed by per-step gradient buffers, and are joined once at
         # the end: the dgrad chain on this stream never waits for them.
-        deferred = bool(lib.nfk_get_aux_stream()) and eng.grad_hook is None
+        deferred = bool(eng.aux) and eng.grad_hook is None
         ga_off, ga_total, wslab_max = {}, 0, 4
         if deferred:
             for r in recs:
@@ -825,6 +834,7 @@ class _EncodeFn(torch.autograd.Function):
                 blk = r.mod.block
                 gs = Step2dGrads()
                 gs.relu_masks = ptr(masks)
+                gs.bwd_mode, gs.aux = eng.bwd_mode, eng.aux
                 gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
                 gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
                 gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
@@ -859,6 +869,7 @@ class _EncodeFn(torch.autograd.Function):
                 blk = r.mod.block
                 gs = Step2dGrads()
                 gs.relu_masks = ptr(masks)
+                gs.bwd_mode, gs.aux = eng.bwd_mode, eng.aux
                 gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
                 gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
                 gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
@@ -906,7 +917,7 @@ class _EncodeFn(torch.autograd.Function):
                     g = gx if not first else gx.permute(0, 3, 1, 2)
 
         if deferred:
-            check(lib.nfk_aux_join(s), "nfk_aux_join")
+            check(lib.nfk_aux_join(eng.aux, s), "nfk_aux_join")
         # parameter-side chain for all steps in one launch
         pg = []
         for r in recs:

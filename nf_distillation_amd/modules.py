@@ -271,6 +271,52 @@ class FlowStep(nn.Module):
         return self.forward(input, y_onehot, logdet, True)
 
 
+def made_masks(d, hidden, ncond=0):
+    """Autoregressive masks of a MADE whose MLP has the shape of get_block_1d (Germain et al. 2015; MAF, Papamakarios et
+    al. 2017): input degrees 1..d (condition features 0: visible to everything), hidden degrees cycling over 1..d-1,
+    hidden->hidden allowed when degree_out >= degree_in, output (mu_i, alpha_i interleaved) allowed when i+1 > degree_in."""
+    deg_in = torch.cat([torch.arange(1, d + 1), torch.zeros(ncond, dtype=torch.long)])
+    deg_h = torch.arange(hidden) % max(d - 1, 1) + 1
+    deg_out = torch.arange(1, d + 1).repeat_interleave(2)
+    masks = [(deg_h[:, None] >= deg_in[None, :]).float()]
+    masks += [(deg_h[:, None] >= deg_h[None, :]).float() for _ in range(4)]
+    masks.append((deg_out[:, None] > deg_h[None, :]).float())
+    return masks
+
+
+class MADEStep(nn.Module):
+    """One block of a masked autoregressive flow -- BASELINE.json / north_star name "MAF MADE blocks"; the reference
+    repository has NO such code (its README mentions MAF once), so this follows the published
+    algorithm (Papamakarios et al. 2017, eq. 3-5) in the reference's own building blocks and is PARITY UNPINNED:
+        ActNorm1d -> reverse permutation -> u_i = (y_i - mu_i(y_<i)) * exp(-alpha_i(y_<i)),  log|det| = -sum alpha_i
+    with (mu, alpha) from a MADE: the get_block_1d MLP (models/flows.py:37-52) whose weights are multiplied with
+    autoregressive masks.  Runs as ONE fused launch per direction through the tabular kernels (nfk_tab_step.made)."""
+
+    is_1d = True
+    flow_coupling = "made"
+    flow_permutation_type = "reverse"
+
+    def __init__(self, in_channels, hidden_channels, actnorm_scale=1.0, condition_features=0):
+        super().__init__()
+        if in_channels < 2:
+            raise ValueError("a MADE block needs at least 2 features")
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.condition_features = condition_features
+        self.actnorm = ActNorm1d(in_channels, actnorm_scale)
+        self.reverse = Permute2d(in_channels, shuffle=False)
+        self.block = get_block_1d(in_channels + condition_features, 2 * in_channels, hidden_channels)
+        for k, m in enumerate(made_masks(in_channels, hidden_channels, condition_features)):
+            self.register_buffer(f"mask{k}", m)
+
+    def masks(self):
+        return [getattr(self, f"mask{k}") for k in range(6)]
+
+    def forward(self, input, y_onehot=None, logdet=None, reverse=False):
+        from .engine import run_single_layer
+        return run_single_layer(self, input, y_onehot, logdet, reverse)
+
+
 class FlowNet(nn.Module):
     """models/flows.py:205-295: L x (squeeze, K steps, split)."""
 
@@ -291,6 +337,12 @@ class FlowNet(nn.Module):
                 self.layers.append(SqueezeLayer(factor=2))
                 self.output_shapes.append([-1, Cc, H, W])
             for _ in range(K):
+                if flow_coupling == "made":   # MAF: a stack of MADE blocks (extension: no upstream counterpart)
+                    if not is_1d:
+                        raise NameError("flow_coupling='made' is a 1-D (tabular) block")
+                    self.layers.append(MADEStep(Cc, hidden_channels, actnorm_scale, condition_features))
+                    self.output_shapes.append([-1, Cc])
+                    continue
                 self.layers.append(FlowStep(in_channels=Cc, hidden_channels=hidden_channels,
                                             actnorm_scale=actnorm_scale, flow_permutation=flow_permutation,
                                             flow_coupling=flow_coupling, LU_decomposed=LU_decomposed,

@@ -220,7 +220,7 @@ class DistillationStep:
         self.opt = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay, clip_norm=clip_norm)
         self.reducer = GradAllReducer(self.flat.grad, process_group, bucket_bytes)
         self.world = self.reducer.world
-        self._side = self._aux = None
+        self._side = self._aux = self._aux_handle = None
         self._concurrent = False
         self.set_allreduce_overlap(True)
 
@@ -233,7 +233,11 @@ class DistillationStep:
             self._side = torch.cuda.Stream()
             self._aux = torch.cuda.Stream()
         self._concurrent = bool(on)
-        capi.lib().nfk_set_aux_stream(self._aux.cuda_stream if on else None)
+        if on and self._aux_handle is None:
+            self._aux_handle = capi.lib().nfk_aux_create(self._aux.cuda_stream)
+        eng = self.student.flow.engine() if hasattr(self.student, "flow") else None
+        if eng is not None:
+            eng.aux = self._aux_handle if on else None
 
     def _cond(self, y_onehot):
         """pl_module.py:216-243: y goes to the models iff params["student"]["y_condition"]."""

@@ -194,6 +194,9 @@ def flow_step(sd, cfg, pfx, x, logdet, y_onehot, reverse, perm_indices=None):
         arg = torch.cat((z1, y_onehot), 1) if use_y else z1
         return coupling_net(sd, pfx + "block.", arg, is_1d)
 
+    if coupling == "made":
+        return made_step(sd, cfg, pfx, x, logdet, y_onehot, reverse)
+
     if not reverse:
         z, logdet = actnorm(sd[pfx + "actnorm.bias"], sd[pfx + "actnorm.logs"], x, logdet, False)
         z, logdet = permutation(z, logdet, False)
@@ -225,6 +228,62 @@ def flow_step(sd, cfg, pfx, x, logdet, y_onehot, reverse, perm_indices=None):
     z, logdet = permutation(z, logdet, True)
     z, logdet = actnorm(sd[pfx + "actnorm.bias"], sd[pfx + "actnorm.logs"], z, logdet, True)
     return z, logdet
+
+
+def made_masks(d, hidden, ncond=0):
+    """Autoregressive masks (Germain et al. 2015, MADE, eq. 12-13; MAF, Papamakarios et al. 2017, section 3.1) for an MLP of
+    get_block_1d's shape: input degrees 1..d (condition features: 0), hidden degrees cycling over 1..d-1, outputs
+    (mu_i, alpha_i) interleaved with degree i.  PARITY UNPINNED: the reference repository contains no MADE / MAF code
+    (SURVEY.md section 0 F1); this restates the published algorithm, it is not pinned to any reference output."""
+    deg_in = torch.cat([torch.arange(1, d + 1), torch.zeros(ncond, dtype=torch.long)])
+    deg_h = torch.arange(hidden) % max(d - 1, 1) + 1
+    deg_out = torch.arange(1, d + 1).repeat_interleave(2)
+    masks = [(deg_h[:, None] >= deg_in[None, :])]
+    masks += [(deg_h[:, None] >= deg_h[None, :]) for _ in range(4)]
+    masks.append(deg_out[:, None] > deg_h[None, :])
+    return masks
+
+
+def made_net(sd, pfx, x, masks):
+    h = x
+    for k, i in enumerate((0, 2, 4, 6)):
+        w = sd[f"{pfx}{i}.weight"]
+        h = torch.relu(F.linear(h, w * masks[k].to(w.dtype), sd[f"{pfx}{i}.bias"]))
+    w = sd[pfx + "8.weight"]
+    h = torch.tanh(F.linear(h, w * masks[4].to(w.dtype), sd[pfx + "8.bias"]))
+    w = sd[pfx + "10.weight"]
+    return F.linear(h, w * masks[5].to(w.dtype), sd[pfx + "10.bias"])
+
+
+def made_step(sd, cfg, pfx, x, logdet, y_onehot, reverse):
+    """One MAF block: ActNorm1d -> reversal of the feature order -> u_i = (y_i - mu_i(y_<i)) exp(-alpha_i(y_<i)),
+    log|det| = -sum_i alpha_i (Papamakarios et al. 2017, eq. 3-5); the inverse fixes one feature per pass (eq. 2).
+    PARITY UNPINNED (see made_masks)."""
+    d = x.shape[1]
+    ncond = cond_features(cfg)
+    hidden = sd[pfx + "block.0.weight"].shape[0]
+    masks = made_masks(d, hidden, ncond)
+    rev_idx = torch.arange(d - 1, -1, -1)
+
+    def net(y):
+        arg = torch.cat((y, y_onehot), 1) if ncond else y
+        h = made_net(sd, pfx + "block.", arg, masks)
+        return h[:, 0::2], h[:, 1::2]
+
+    if not reverse:
+        z, logdet = actnorm(sd[pfx + "actnorm.bias"], sd[pfx + "actnorm.logs"], x, logdet, False)
+        y = z[:, rev_idx]
+        mu, alpha = net(y)
+        return (y - mu) * torch.exp(-alpha), logdet - alpha.sum(1)
+    u = x
+    y = torch.zeros_like(u)
+    for i in range(d):
+        mu, alpha = net(y)
+        y = torch.cat((y[:, :i], (u[:, i] * torch.exp(alpha[:, i]) + mu[:, i])[:, None], y[:, i + 1:]), 1)
+    mu, alpha = net(y)
+    logdet = logdet + alpha.sum(1)
+    z = y[:, rev_idx]
+    return actnorm(sd[pfx + "actnorm.bias"], sd[pfx + "actnorm.logs"], z, logdet, True)
 
 
 def split2d(sd, pfx, x, logdet, reverse, temperature=None, eps=None):

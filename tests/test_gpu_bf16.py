@@ -185,27 +185,27 @@ def test_fused_step_variants(variant):
 
 
 def _grads_with(mode, halo, g, cfg, sd, x, noise, chain=False):
+    """mode: 0 separate launches, 1 dual launches for small steps, 2 dual launches (nfk_step2d_grads.bwd_mode - 1)"""
     from nf_distillation_amd import capi
     lib = capi.lib()
-    lib.nfk_set_bwd_mode(mode)
-    lib.nfk_set_tuning(3001 if halo else 3000)   # conv1 dgrad through the halo-tile kernel or the split-K GEMM
-    lib.nfk_set_tuning(3011 if halo else 3010)   # conv3 weight gradient through the halo-tile kernel or the generic one
+    lib.nfk_tune(capi.TUNE_NARROW_HALO_DGRAD, 1 if halo else 0)   # conv1 dgrad through the halo-tile kernel or the split-K GEMM
+    lib.nfk_tune(capi.TUNE_WGRAD_HALO, 1 if halo else 0)          # conv3 weight gradient through the halo-tile kernel or the generic one
     try:
         model = build(cfg, sd)
         model.flow.engine().chain_backward = chain
+        model.flow.engine().bwd_mode = mode + 1
         outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
         bpd.mean().backward()
         torch.cuda.synchronize()
         return {k: p.grad.cpu() for k, p in model.named_parameters()}
     finally:
-        lib.nfk_set_bwd_mode(3)
-        lib.nfk_set_tuning(3001)
-        lib.nfk_set_tuning(3011)
+        lib.nfk_tune(capi.TUNE_NARROW_HALO_DGRAD, 1)
+        lib.nfk_tune(capi.TUNE_WGRAD_HALO, 1)
 
 
 def test_dual_dgrad_wgrad_launch_is_bit_identical():
-    """bf16 backward: a conv's dgrad GEMM and weight-gradient GEMM run as ONE launch (nfk_set_bwd_mode 2, default) or as
-    two (mode 0).  Same tiles, same split-K, same summation order: every gradient must agree bit for bit.  (With the
+    """bf16 backward: a conv's dgrad GEMM and weight-gradient GEMM run as ONE launch (NFK_BWD_DUAL) or as
+    two (NFK_BWD_SEPARATE).  Same tiles, same split-K, same summation order: every gradient must agree bit for bit.  (With the
     halo-tile kernel for conv1's dgrad, which sums the taps in another order, the gradients agree to rounding: next test.)"""
     g = Golden("cifar_k8_full")
     cfg = g.cfg

@@ -123,12 +123,12 @@ def test_aux_stream_deferred_join_is_bit_identical():
     g = Golden("distill8")
     res = []
     try:
-        capi.lib().nfk_set_bwd_mode(0)
         for concurrent in (False, True):
             student = _build(g.cfg["student"], g.group("s_sd"))
             teacher = _build(g.cfg["teacher"], g.group("t_sd"))
             student.set_compute_dtype("bf16")
             teacher.set_compute_dtype("bf16")
+            student.flow.engine().bwd_mode = capi.BWD_SEPARATE
             step = DistillationStep(student, teacher)
             step.enable_concurrency(concurrent)
             for i in range(2):
@@ -138,8 +138,7 @@ def test_aux_stream_deferred_join_is_bit_identical():
             step.enable_concurrency(False)
             res.append({k: v.cpu() for k, v in student.state_dict().items()})
     finally:
-        capi.lib().nfk_set_bwd_mode(3)   # the library's default
-        capi.lib().nfk_set_aux_stream(None)
+        pass
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
 

@@ -26,7 +26,7 @@ def run(shape, tune, iters=30):
     S = lib.nfk_conv_splitk(M, N, K) if epi == 0 else 1
     out = torch.empty(S * M * N, device=dev)
     e0, e1 = torch.randn(N, device=dev), torch.rand(N, device=dev) + 0.5
-    lib.nfk_set_tuning(tune)
+    lib.nfk_tune(capi.TUNE_F32_TILES, tune)
     s = capi.stream()
     for _ in range(3):
         check(lib.nfk_conv(ptr(x), Cin, B, H, W, Cin, taps, ptr(wt), N, ptr(out), N, epi, ptr(e0), ptr(e1), s))
@@ -37,7 +37,7 @@ def run(shape, tune, iters=30):
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / iters
-    lib.nfk_set_tuning(0)
+    lib.nfk_tune(capi.TUNE_F32_TILES, 0)
     return us, 2.0 * M * N * K / (us * 1e-6) / 1e12
 
 
