@@ -237,6 +237,17 @@ int nfk_step2d_bwd_deferred(const nfk_step2d *s, const nfk_step2d_grads *g, cons
  *   coupling_rows 0: this call runs its own coupling backward (as nfk_step2d_bwd); > 0: the previous call already did,
  *                 passing this step as `next`, and left that many partial rows (the value it returned in *next_rows).
  * Same B, H, W, C for both steps.  ga / wslab as in nfk_step2d_bwd_deferred (NULL, NULL = nfk_step2d_bwd). */
+/* pending (optional, with the fused backward and no auxiliary-stream deferral): lets a call put its three weight-gradient
+ * GEMMs into ONE launch with the channel mix that ends the step (two launches on a step's critical path instead of
+ * three).  The reductions that wait for those GEMMs -- split slabs into the weight gradients, ActNorm partial rows -- are
+ * then owed: the call stores them in `pending`, the next call (any geometry) takes them into its own merged launch, and
+ * nfk_step2d_pending_flush runs what is owed after the last one.  A caller zero-initialises the struct once per
+ * backward and must keep the workspace of the owing call untouched until the next call / the flush has been enqueued
+ * (two workspaces used alternately do). */
+typedef struct nfk_step2d_pending {
+  int32_t valid, pad_;
+  uint64_t blob[40];
+} nfk_step2d_pending;
 typedef struct nfk_step2d_next {
   const nfk_step2d *s;
   const float *z, *hsave;   /* saved by that step's forward */
@@ -246,7 +257,8 @@ typedef struct nfk_step2d_next {
 int nfk_step2d_bwd_chain(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
                          const float *h1, const float *h2, const float *hsave, const float *g_out, const float *g_ext,
                          const float *g_ld, float *g_x, float *ws, float *ga, float *wslab, int coupling_rows,
-                         const nfk_step2d_next *next, int *next_rows, void *stream);
+                         const nfk_step2d_next *next, int *next_rows, nfk_step2d_pending *pending, void *stream);
+int nfk_step2d_pending_flush(nfk_step2d_pending *pending, void *stream);
 size_t nfk_step2d_bwd_ga_floats(const nfk_step2d *s);
 size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d *s);
 int nfk_aux_join(nfk_aux *aux, void *stream);

@@ -64,6 +64,11 @@ class FusedRun(C.Structure):
                 ("masksave", c_fp), ("mask_stride", C.c_int64), ("ldpart", c_fp)]
 
 
+class Step2dPending(C.Structure):
+    """nfk_step2d_pending: the slab / partial-row reductions a merged weight-gradient launch leaves to the next call."""
+    _fields_ = [("valid", C.c_int32), ("pad_", C.c_int32), ("blob", C.c_uint64 * 40)]
+
+
 class Step2dNext(C.Structure):
     _fields_ = [("s", C.POINTER(Step2d)), ("z", c_fp), ("hsave", c_fp), ("g_ext", c_fp), ("ws", c_fp), ("ga", c_fp)]
 
@@ -147,7 +152,8 @@ _PROTOS = {
     "nfk_step2d_bwd_deferred": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp, vp, vp]),
     "nfk_step2d_bwd_chain": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp,
-                                   vp, vp, vp, vp, i32, C.POINTER(Step2dNext), C.POINTER(i32), vp]),
+                                   vp, vp, vp, vp, i32, C.POINTER(Step2dNext), C.POINTER(i32), C.POINTER(Step2dPending), vp]),
+    "nfk_step2d_pending_flush": (i32, [C.POINTER(Step2dPending), vp]),
     "nfk_step2d_bwd_ga_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_bwd_wslab_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_aux_join": (i32, [vp, vp]),

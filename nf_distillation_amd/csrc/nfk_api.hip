@@ -282,12 +282,27 @@ int nfk_step2d_inv(const nfk_step2d* s, const float* y, int ldy, const float* ld
   return launch_chanmix(m, st);
 }
 
+// What a step's backward still owes when its weight-gradient launch has been merged with the channel-mix launch
+// (wgrad_tail_bf16): the reduction of its split slabs and of the ActNorm layers' partial rows -- done by the NEXT step's
+// merged launch, or by nfk_step2d_pending_flush after the last one.
+struct PendingTail {
+  nfk_small_grad_args sg;   // col1 / col2 segments only (n3 = 0)
+  StepTailArgs f;
+};
+static_assert(sizeof(PendingTail) <= sizeof(((nfk_step2d_pending*)nullptr)->blob), "nfk_step2d_pending.blob too small");
+static PendingTail* pending_of(nfk_step2d_pending* p) { return reinterpret_cast<PendingTail*>(p->blob); }
+static int pending_flush(nfk_step2d_pending* p, hipStream_t st) {
+  if (!p || !p->valid) return NFK_OK;
+  p->valid = 0;
+  return launch_step_tail(pending_of(p)->sg, pending_of(p)->f, st);
+}
+
 // ga / wslab_ext: see nfk_step2d_bwd_deferred (both NULL = everything inside ws, auxiliary stream joined per call)
 static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
                            const float* h1, const float* h2, const float* hsave, const float* g_out,
                            const float* g_ext, const float* g_ld, float* g_x, float* ws, float* ga, float* wslab_ext,
                            void* stream, int coupling_rows = 0, const nfk_step2d_next* next = nullptr,
-                           int* next_rows = nullptr) {
+                           int* next_rows = nullptr, nfk_step2d_pending* pend = nullptr) {
   hipStream_t st = S_(stream);
   const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, hid = s->hidden, Cout = s->Cout;
   const int M = B * H * W, HW = H * W, bf = s->bf16;
@@ -297,10 +312,12 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   nfk_aux* const ax = g->aux;
   const int bwd_mode = bwd_mode_of(g);
   const bool deferred = ga != nullptr && wslab_ext != nullptr && ax != nullptr && ax->stream != st;
-  if (deferred) {   // the three tensors the weight-gradient GEMMs read live in this step's own buffer
+  float* x3 = ws + L.x3;
+  if (deferred) {   // the tensors the weight-gradient GEMMs read live in this step's own buffer
     ga3 = ga;
     ga2 = ga3 + align4((size_t)M * Cout);
     ga1 = ga2 + align4((size_t)M * hid);
+    x3 = ga1 + align4((size_t)M * hid);
     wslab = wslab_ext;
   }
 
@@ -363,26 +380,43 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   w1.pbf16 = bf;
   ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
   if (!fgrid) NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
+  bool merged = false;
+  ActnormSumArgs an_m{};
   if (fgrid) {
     // fused backward: the whole dgrad chain in one launch (g_a2 / g_a1 stay in LDS between the convolutions and are
     // written once for the weight gradients), then the three weight-gradient GEMMs in one launch
     FusedBwdCall fc{};
     fc.s = *s; fc.ga3 = ga3; fc.masks = reinterpret_cast<const unsigned char*>(g->relu_masks);
     fc.ga2 = ga2; fc.ga1 = ga1; fc.d1 = d1; fc.stamps = g_bwd_stamps;
-    fc.x3save = ws + L.x3;
+    fc.x3save = x3;
     NFK_TRY(fusedb_launch(fc, st));
+    // Deferred mode (an auxiliary stream and per-step buffers: nfk_step2d_bwd_deferred / _chain): the weight-gradient
+    // launch, the reduction of its slabs and the ActNorm gradients leave the caller's stream -- nothing on the chain
+    // dgrad(s) -> channel mix(s) + coupling backward(s-1) -> dgrad(s-1) ... reads them -- and form a chain of their own
+    // on the auxiliary stream, forked here once per step and joined once per backward (nfk_aux_join).  Their per-channel
+    // partial sums (col1 / col2) then live behind the slabs in `wslab`, which only that stream touches.
+    hipStream_t wst = st;
+    if (deferred) {
+      fork_to_aux(ax, st, 0);
+      wst = ax->stream;
+      col2 = wslab + (L.x3 - L.wslab);
+      col1 = col2 + align4((size_t)L.mb2 * 2 * hid);
+    }
     // conv3 and conv1 as plain pixel-major GEMMs: the 3x3 taps sit in the im2col rows the two fused kernels built anyway
     // (dgrad3's of g_a3 above, conv1's of z1 behind the ReLU masks of the forward), not in nine shifted passes / a
     // per-element gather:  gW3[co][ci][tap] = sum_m x3[m][(8 - tap) Cout + co] h2[m][ci],
     //                      gW1[co][ci][tap] = sum_m g_a1[m][co] x1[m][tap C/2 + ci]
-    w3.P = ws + L.x3; w3.ldp = L.K3p; w3.NI = L.K3p; w3.pbf16 = 1; w3.taps = 1; w3.slab_stride = (long)L.K3p * hid;
+    w3.P = x3; w3.ldp = L.K3p; w3.NI = L.K3p; w3.pbf16 = 1; w3.taps = 1; w3.slab_stride = (long)L.K3p * hid;
     w1.Q = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(g->relu_masks) + (size_t)2 * M * (hid / 8));
     w1.ldq = L.K1p; w1.Cq = L.K1p; w1.taps = 1; w1.qbf16 = 1; w1.slab_stride = (long)hid * L.K1p;
     ActnormSumArgs an{};
     an.ga2 = ga2; an.h2 = h2; an.ga1 = ga1; an.h1 = h1; an.es2 = s->es2; an.es1 = s->es1; an.col2 = col2; an.col1 = col1;
     an.M = M; an.hid = hid; an.nparts = actnorm_sum_parts(M);
     mb1 = mb2 = an.nparts;
-    NFK_TRY(triple_wgrad_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an, st, (double)hid * (9.0 * Cout + hid + 9.0 * Ch)));
+    merged = pend != nullptr && !deferred;   // the GEMMs share ONE launch with the channel mix below (wgrad_tail_bf16)
+    an_m = an;
+    if (!merged)
+      NFK_TRY(triple_wgrad_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an, wst, (double)hid * (9.0 * Cout + hid + 9.0 * Ch)));
     const WgradArgs* ws3[3] = {&w3, &w2, &w1};
     const int Sw[3] = {L.S3f, L.S2w, L.S1f}, Co[3] = {Cout, hid, hid}, Ci[3] = {hid, hid, Ch}, tp[3] = {9, 1, 9};
     const int md[3] = {1, 0, 0}, lj[3] = {hid, 0, L.K1p};
@@ -392,15 +426,26 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
       tail_f.S[k] = Sw[k]; tail_f.Cout[k] = Co[k]; tail_f.Cin[k] = Ci[k]; tail_f.taps[k] = tp[k];
       tail_f.mode[k] = md[k]; tail_f.ldj[k] = lj[k];
     }
+    if (deferred) {   // slab reductions + the two ActNorm layers' gradients: behind the GEMMs on the auxiliary stream
+      nfk_small_grad_args sa{};
+      sa.col1 = col1; sa.col2 = col2; sa.mb1 = mb1; sa.mb2 = mb2; sa.n1 = hid; sa.n2 = hid; sa.n3 = 0;
+      sa.g_l1 = g->g_l1; sa.g_b1 = g->g_b1; sa.g_l2 = g->g_l2; sa.g_b2 = g->g_b2;
+      NFK_TRY(launch_step_tail(sa, tail_f, wst));
+      tail_f = StepTailArgs{};   // nothing of it is left for the caller's stream
+    }
   }
+  const bool fused_deferred = fgrid && deferred;
 
   nfk_small_grad_args sg{};
   sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = mb1; sg.mb2 = mb2;
   sg.B = coupling_rows > 0 ? coupling_rows : B;
-  sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
+  sg.n1 = fused_deferred ? 0 : hid; sg.n2 = fused_deferred ? 0 : hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
   sg.g_l3 = g->g_l3;
-  const bool have_tail = (tail_f.S[0] | tail_f.S[1] | tail_f.S[2]) != 0;
+  // (fused + deferred: the caller's stream still runs the one launch of coupling-tail gradients + channel mix + the next
+  //  step's coupling backward, only without slab work)
+  const bool have_tail = fused_deferred || (tail_f.S[0] | tail_f.S[1] | tail_f.S[2]) != 0;
+  if (pend && pend->valid && !merged) NFK_TRY(pending_flush(pend, st));   // this call cannot take the previous step's tail along
 
   // actnorm + permutation backward: g_x = Wf^T g_z, partial (gWf, gcf) for nfk_prep_bwd
   ChanMixArgs m{};
@@ -423,7 +468,32 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
     nb.ldgz = C; nb.part = next->ws + Ln.tail; nb.HW = HW; nb.C = C; nb.Cout = n->Cout; nb.additive = n->additive;
     chained = true;
   }
-  if (have_tail) {
+  if (merged) {
+    // ONE launch: this step's GEMMs || channel mix + next step's coupling backward + this step's coupling-tail gradients
+    // || the PREVIOUS step's slab / partial-row reductions (its GEMMs finished two launches ago); this step's own
+    // reductions become the next call's (or nfk_step2d_pending_flush's)
+    nfk_small_grad_args sx = sg;       // coupling-tail segment (n3): this step's; col1 / col2 segments: the previous step's
+    StepTailArgs fx{};
+    sx.n1 = sx.n2 = 0;
+    if (pend->valid) {
+      const PendingTail* pt = pending_of(pend);
+      sx.col1 = pt->sg.col1; sx.col2 = pt->sg.col2; sx.mb1 = pt->sg.mb1; sx.mb2 = pt->sg.mb2; sx.n1 = pt->sg.n1; sx.n2 = pt->sg.n2;
+      sx.g_l1 = pt->sg.g_l1; sx.g_b1 = pt->sg.g_b1; sx.g_l2 = pt->sg.g_l2; sx.g_b2 = pt->sg.g_b2;
+      fx = pt->f;
+    }
+    int rc = wgrad_tail_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an_m, sx, fx, m, chained ? &nb : nullptr, st,
+                             (double)hid * (9.0 * Cout + hid + 9.0 * Ch));
+    if (rc == NFK_ERR_ARG && chained) {   // the coupling backward does not fit beside the channel mix: unchained
+      chained = false;
+      rc = wgrad_tail_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an_m, sx, fx, m, nullptr, st, (double)hid * (9.0 * Cout + hid + 9.0 * Ch));
+    }
+    if (rc != NFK_OK) return rc;
+    if (chained && next_rows) *next_rows = chanmix_parts(M, C);
+    PendingTail* pt = pending_of(pend);
+    pt->sg = sg; pt->sg.n3 = 0; pt->sg.tail = nullptr;
+    pt->f = tail_f;
+    pend->valid = 1;
+  } else if (have_tail) {
     int rc = launch_tail_chanmix(sg, tail_f, m, chained ? &nb : nullptr, st);
     if (rc == NFK_OK && chained && next_rows) *next_rows = chanmix_parts(M, C);
     if (rc == NFK_ERR_ARG && chained) rc = launch_tail_chanmix(sg, tail_f, m, nullptr, st);   // does not fit: unchained
@@ -455,17 +525,19 @@ int nfk_step2d_bwd_deferred(const nfk_step2d* s, const nfk_step2d_grads* g, cons
 int nfk_step2d_bwd_chain(const nfk_step2d* s, const nfk_step2d_grads* g, const float* x, int ldx, const float* z,
                          const float* h1, const float* h2, const float* hsave, const float* g_out, const float* g_ext,
                          const float* g_ld, float* g_x, float* ws, float* ga, float* wslab, int coupling_rows,
-                         const nfk_step2d_next* next, int* next_rows, void* stream) {
+                         const nfk_step2d_next* next, int* next_rows, nfk_step2d_pending* pending, void* stream) {
   return step2d_bwd_impl(s, g, x, ldx, z, h1, h2, hsave, g_out, g_ext, g_ld, g_x, ws, ga, wslab, stream, coupling_rows,
-                         next, next_rows);
+                         next, next_rows, pending);
 }
+int nfk_step2d_pending_flush(nfk_step2d_pending* pending, void* stream) { return pending_flush(pending, S_(stream)); }
 size_t nfk_step2d_bwd_ga_floats(const nfk_step2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;
-  return align4(M * s->Cout) + 2 * align4(M * s->hidden);
+  const StepBwdWs L = step_bwd_layout(s);
+  return align4(M * s->Cout) + 2 * align4(M * s->hidden) + align4((M * L.K3p + 1) / 2);   // g_a3, g_a2, g_a1, dgrad3's im2col rows
 }
 size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d* s) {
   const StepBwdWs L = step_bwd_layout(s);
-  return L.total - L.wslab;
+  return (L.x3 - L.wslab) + align4((size_t)L.mb2 * 2 * s->hidden) + align4((size_t)L.mb1 * 2 * s->hidden);   // slabs, col2, col1
 }
 void nfk_debug_triple_parts(int skip_mask) { triple_wgrad_debug_skip(skip_mask); }
 void nfk_fused_bwd_set_stamps(void* buf) { g_bwd_stamps = reinterpret_cast<unsigned long long*>(buf); }

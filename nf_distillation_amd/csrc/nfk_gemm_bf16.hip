@@ -9,6 +9,7 @@
 //     (z1, g_a3: C <= 96 channels) stay fp32 in HBM and are converted while staging (XF32)
 #include "nfk_internal.h"
 #include "nfk_repack.h"
+#include "nfk_tail.h"
 
 namespace nfk {
 
@@ -980,6 +981,79 @@ __global__ void __launch_bounds__(256) triple_wgrad_bf16_kernel(WgradArgs w2, in
   }
   b -= n3;
   wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1);
+}
+
+// The weight-gradient launch of a step merged with the launch that used to follow it (tail_chanmix_kernel): nothing in
+// the latter waits for the GEMMs of ITS OWN step except the slab reductions -- so those are taken from the PREVIOUS step
+// of the backward (whose GEMMs finished two launches ago; the caller carries them along: nfk_step2d_pending), and the
+// channel mix + next step's coupling backward + this step's coupling-tail gradients, which only wait for the dgrad
+// launch, run beside the GEMMs.  A step's backward is then two launches on the critical path instead of three:
+//   [fused dgrad chain]  [this: channel mix + coupling backward(next) || ActNorm sums || 3 GEMMs || slab reductions(previous)]
+// Block order: the channel-mix workgroups first (few, each a chain of dependent loads: the next launch waits for them).
+__global__ void __launch_bounds__(256) wgrad_tail_kernel(WgradArgs w2, int nb2, int S2, WgradArgs w1, int nb1, int S1, WgradArgs w3,
+                                                         int nb3, int S3, ActnormSumArgs an, int n_cm, ChanMixArgs m,
+                                                         CouplingBwdArgs nx, SmallGradArgs sg, StepTailArgs tf) {
+  int b = blockIdx.x;
+  if (b < n_cm) {
+    if (nx.ga3) chanmix_body<true>(m, b, n_cm, nx);
+    else chanmix_body<false>(m, b, n_cm, nx);
+    return;
+  }
+  b -= n_cm;
+  if (b < an.nparts) { actnorm_sum_body(an, b); return; }
+  b -= an.nparts;
+  if (b < nb2 * S2) { wgrad_bf16_body<4, 4, 2, 2>(w2, b % nb2, S2, b / nb2); return; }
+  b -= nb2 * S2;
+  if (b < nb3 * S3) { wgrad_bf16_body<4, 4, 2, 2>(w3, b % nb3, S3, b / nb3); return; }
+  b -= nb3 * S3;
+  if (b < nb1 * S1) { wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1); return; }
+  b -= nb1 * S1;
+  step_tail_body(sg, tf, b);
+}
+
+int wgrad_tail_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an,
+                    const SmallGradArgs& sg, StepTailArgs tf, const ChanMixArgs& m, const CouplingBwdArgs* next, hipStream_t st,
+                    double alg_nj) {
+  for (WgradArgs* w : {&w3, &w2, &w1}) {
+    w->M = w->B * w->H * w->W;
+    w->J = w->taps * w->Cq;
+    if (w->M <= 0 || w->NI <= 0 || w->J <= 0) return NFK_ERR_ARG;
+    if ((long)w->M * w->ldp * 4 >= 0x7fffffffL || (long)w->M * w->ldq * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
+    if (!w->pbf16 || !w->qbf16 || w->taps != 1 || ((w->NI | w->ldp | w->Cq | w->ldq) & 7)) return NFK_ERR_ARG;
+  }
+  if (an.hid != 512 || an.nparts < 1) return NFK_ERR_ARG;
+  // channel-mix part: as launch_tail_chanmix
+  const int C = m.C, Cp = (C + 3) & ~3, TP = cm_tile_pixels(C), C2 = C - C / 2;
+  size_t lds_cm = (size_t)(C * Cp + 2 * TP * (C + 1) + (m.part ? C * C + C : 0)) * sizeof(float);
+  CouplingBwdArgs nx{};
+  if (next) {
+    if (C2 < 1 || C2 > 256) return NFK_ERR_ARG;
+    nx = *next;
+    lds_cm += (size_t)(TP * (C + 1) + (256 / C2) * 4 * C2 + 4 * C2) * sizeof(float);
+  }
+  if (lds_cm > 64 * 1024 || m.M <= 0) return NFK_ERR_ARG;
+  int cb = ceil_div(m.M, TP);
+  if (m.part && cb > CM_MAX_BLOCKS) cb = CM_MAX_BLOCKS;
+  constexpr size_t ldsWide = 2 * WPX * (wg_stride(128) + wg_stride(128));
+  const size_t lds = ldsWide > lds_cm ? ldsWide : lds_cm;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  const int nb2 = ceil_div(w2.NI, 128) * ceil_div(w2.J, 128), nb1 = ceil_div(w1.NI, 128) * ceil_div(w1.J, 128);
+  const int nb3 = ceil_div(w3.NI, 128) * ceil_div(w3.J, 128);
+  const int nt = tail_blocks(sg, tf);
+  const int cls = NFK_PROF_TRIPLE_WGRAD + (w2.M >= 8192 ? 0 : (w2.M >= 2048 ? 1 : 2));
+  const double nj = alg_nj > 0 ? alg_nj : ((double)w2.NI * w2.J + (double)w1.NI * w1.J + (double)w3.NI * w3.J);
+  prof_scope_begin(cls, 2.0 * w2.M * nj,
+                   w2.M * (2.0 * w2.NI + 2.0 * w2.Cq + 2.0 * w1.NI + 4.0 * w1.Cq + 4.0 * w3.NI + 2.0 * w3.Cq) +
+                       4.0 * (S2 * (double)w2.NI * w2.J + S1 * (double)w1.NI * w1.J + S3 * (double)w3.NI * w3.J), st);
+  hipLaunchKernelGGL(wgrad_tail_kernel, dim3(cb + an.nparts + nb2 * S2 + nb3 * S3 + nb1 * S1 + nt), dim3(256), lds, st, w2, nb2, S2,
+                     w1, nb1, S1, w3, nb3, S3, an, cb, m, nx, sg, tf);
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
 }
 
 static int g_triple_skip = 0;

@@ -219,5 +219,10 @@ int launch_step_tail(const SmallGradArgs& a, StepTailArgs f, hipStream_t st);
 // its partial rows are then one per channel-mix workgroup (chanmix_parts(M, C)), not one per sample
 int launch_tail_chanmix(const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, const CouplingBwdArgs* next,
                         hipStream_t st);
+// the step's three weight-gradient GEMMs (all operands pixel-major bf16: the fused backward's) + everything of
+// launch_tail_chanmix in ONE launch; `f` / the col1, col2 part of `a` describe the PREVIOUS step's slabs and partial rows
+int wgrad_tail_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, int S1, const ActnormSumArgs& an,
+                    const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, const CouplingBwdArgs* next, hipStream_t st,
+                    double alg_nj);
 
 }  // namespace nfk

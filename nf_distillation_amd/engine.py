@@ -59,10 +59,14 @@ class FlowEngine:
         self.fused_split_inference = 4   # ways: 4, 2, 0 (none) or "frugal" (see _EncodeFn.forward)
         self.fused_split_training = 4    # the same for a forward that keeps what the backward needs
         self.chain_backward = True       # nfk_step2d_bwd_chain (False: one independent nfk_step2d_bwd call per step)
+        # fused backward: a step's weight-gradient GEMMs share ONE launch with the channel mix that ends the step; the slab
+        # reductions that wait for them ride on the next step's launch (nfk_step2d_pending)
+        self.merge_wgrad_tail = True
         # all FlowSteps of a level in ONE launch where the pixel tiles are whole images (nfk_run2d_fwd_fused; bit-identical
         # to the per-step launches without hidden split).  "inference": only for passes that keep nothing (a frozen teacher)
         self.fused_runs = True
         self.bwd_mode = capi.BWD_DEFAULT   # nfk_step2d_grads.bwd_mode: how the bf16 backward of a coupling net is launched
+        self.defer_fused_wgrad = False   # bf16 fused backward: weight-gradient launches as a chain of their own on `aux`
         self.aux = None        # nfk_aux handle (training.enable_concurrency): auxiliary stream of the weight-gradient GEMMs
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
@@ -795,7 +799,9 @@ class _EncodeFn(torch.autograd.Function):
         # With an auxiliary stream (training.enable_concurrency) and no per-layer gradient hook, the weight-gradient
         # GEMMs of ALL steps form one chain on that stream, fed by per-step gradient buffers, and are joined once at
         # the end: the dgrad chain on this stream never waits for them.
-        deferred = bool(eng.aux) and eng.grad_hook is None
+        # (bf16: the dual / fused launches keep everything on one stream unless defer_fused_wgrad asks for the separate
+        #  weight-gradient chain -- bit-identical, but measured slower inside a replayed hipGraph: 24 more cross-stream edges)
+        deferred = bool(eng.aux) and eng.grad_hook is None and (not eng.bf16 or eng.defer_fused_wgrad)
         ga_off, ga_total, wslab_max = {}, 0, 4
         if deferred:
             for r in recs:
@@ -816,6 +822,8 @@ class _EncodeFn(torch.autograd.Function):
         ws_pair = [torch.empty(ws_max, device=dev, dtype=torch.float32) for _ in range(2)] if eng.chain_backward else None
         order = list(zip(reversed(recs), reversed(ctx.saved), reversed(g_outs)))
         ext_of = {}
+        # (a per-layer gradient hook wants every layer's gradients final when its call returns: no owed reductions then)
+        pend = capi.Step2dPending() if (eng.merge_wgrad_tail and eng.bf16 and eng.grad_hook is None and ws_pair is not None) else None
 
         def _ext(i):
             if i not in ext_of:
@@ -857,7 +865,8 @@ class _EncodeFn(torch.autograd.Function):
                 check(lib.nfk_step2d_bwd_chain(C.byref(r.cs), C.byref(gs), ptr(x_in), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
                                                ptr(g_main), ptr(g_ext), ptr(g_ld), ptr(gx), ptr(ws),
                                                (ga_all.data_ptr() + 4 * ga_off[r.idx]) if deferred else None,
-                                               ptr(wslab) if deferred else None, rows_in, nxt_p, C.byref(rows_out), s),
+                                               ptr(wslab) if deferred else None, rows_in, nxt_p, C.byref(rows_out),
+                                               C.byref(pend) if pend is not None else None, s),
                       "nfk_step2d_bwd_chain")
                 rows_in = rows_out.value
                 n_step += 1
@@ -916,6 +925,8 @@ class _EncodeFn(torch.autograd.Function):
                     check(lib.nfk_unsqueeze(ptr(tot), ptr(gx), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze")
                     g = gx if not first else gx.permute(0, 3, 1, 2)
 
+        if pend is not None:
+            check(lib.nfk_step2d_pending_flush(C.byref(pend), s), "nfk_step2d_pending_flush")
         if deferred:
             check(lib.nfk_aux_join(eng.aux, s), "nfk_aux_join")
         # parameter-side chain for all steps in one launch

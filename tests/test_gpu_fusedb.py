@@ -92,3 +92,32 @@ def test_fused_backward_celeba_student_falls_back():
     dual, _ = _grads(2, cfg, sd, x, noise)
     for k in fused:
         assert torch.equal(fused[k], dual[k]), k
+
+
+def test_fused_backward_weight_gradients_on_the_auxiliary_stream_bit_identical():
+    """engine.defer_fused_wgrad: per step, the weight-gradient launch, its slab reductions and the ActNorm gradients leave
+    the dgrad chain's stream for a chain of their own on the auxiliary stream (one fork per step, one join per backward;
+    nfk_step2d_bwd_chain with ga / wslab).  Same kernels, same summation orders: every gradient bit for bit.  (Kept off by
+    default: inside a replayed hipGraph the 24 extra cross-stream edges cost more than the concurrency returns.)"""
+    from nf_distillation_amd import capi
+    g = Golden("cifar_k8_full")
+    cfg = g.cfg
+    sd = randomize_state_dict(full_shapes(cfg), int(g.t("seed")))
+    h, w, c = cfg["image_shape"]
+    x, noise = synthetic_images(4, (c, h, w), seed=int(g.t("seed")) + 21)
+    res = []
+    side = torch.cuda.Stream()
+    aux = capi.lib().nfk_aux_create(side.cuda_stream)
+    try:
+        for defer in (False, True):
+            model = build(cfg, sd)
+            eng = model.flow.engine()
+            eng.aux, eng.defer_fused_wgrad = (aux if defer else None), defer
+            outs, bpd, _ = model(x.clone().cuda(), None, noise=noise.cuda())
+            (bpd.mean() + 0.05 * sum(o.square().mean() for o in outs[::7])).backward()
+            torch.cuda.synchronize()
+            res.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    finally:
+        capi.lib().nfk_aux_destroy(aux)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
