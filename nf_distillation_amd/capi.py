@@ -207,26 +207,28 @@ def lib():
 
 PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
                 "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>",
-                "fused2_step_fwd_kernel<*,1,*> (FlowStep forward, Cout <= 16: CIFAR level 1 = <3,1,4,1>)",
-                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8,NS>)",
-                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <2,3,16,NS>)",
+                "fused2_step_fwd_kernel<*,1,*> (FlowStep forward, Cout <= 16: CIFAR level 1 = <3,1,4,1,false>)",
+                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8,1,true>: one launch per "
+                "run of steps, flops and bytes of the whole run)",
+                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <2,3,16,1,true>: one launch per "
+                "run of steps, flops and bytes of the whole run)",
                 ) + tuple(f"dual_dgrad_wgrad_bf16_kernel {conv}, {lvl}"
                           for conv in ("conv3 (block.4: wide dgrad + narrow wgrad)", "conv2 (block.2: 512x512)",
                                        "conv1 (block.0: narrow dgrad + wide wgrad)")
                           for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)")) \
     + tuple(f"{k}, {lvl}" for k in ("fusedb_step_bwd_kernel (FlowStep backward: dgrad3 -> dgrad2 -> dgrad1 in one launch)",
-                                    "triple_wgrad_bf16_kernel (the step's three weight-gradient GEMMs in one launch)")
+                                    "wgrad_tail_kernel (the step's three weight-gradient GEMMs + channel mix + the previous step's slab reductions in one launch)")
             for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)"))
 
 
 # class -> rocprofv3 symbol of the instance the student's chain launches at CIFAR B=64 (tools/pmc_traffic.py, bench.py `traffic`)
 PROF_SYMBOLS = {
-    PROF_CLASSES[5]: "nfk::fused2_step_fwd_kernel<3, 1, 4, 1>",
-    PROF_CLASSES[6]: "nfk::fused2_step_fwd_kernel<2, 2, 8, 1>",
-    PROF_CLASSES[7]: "nfk::fused2_step_fwd_kernel<2, 3, 16, 4>",
-    PROF_CLASSES[8]: "nfk::dual_dgrad_wgradhalo_bf16_kernel<2, 2, 2, 2, true>",
-    PROF_CLASSES[11]: "nfk::dual_dgrad_wgrad_bf16_kernel<4, 4, 2, 2, false, 4, 4, 2, 2>",
-    PROF_CLASSES[14]: "nfk::dual_halo_dgrad_wgrad_bf16_kernel<1, 4, 4, 2, 2>",
+    PROF_CLASSES[5]: "nfk::fused2_step_fwd_kernel<3, 1, 4, 1, false>",
+    PROF_CLASSES[6]: "nfk::fused2_step_fwd_kernel<2, 2, 8, 1, true>",
+    PROF_CLASSES[7]: "nfk::fused2_step_fwd_kernel<2, 3, 16, 1, true>",
+    PROF_CLASSES[17]: "nfk::fusedb_step_bwd_kernel<3, 1, 8>",
+    PROF_CLASSES[18]: "nfk::fusedb_step_bwd_kernel<2, 1, 16>",
+    PROF_CLASSES[19]: "nfk::fusedb_step_bwd_kernel<2, 2, 28>",
 }
 
 
