@@ -123,13 +123,15 @@ class Leg:
             # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
             # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py)
             from nf_distillation_amd.pipeline import PipelinedStep
-            self.runner = PipelinedStep(self.step, data[0], strict=True)
+            self.runner = PipelinedStep(self.step, data[0], strict=self.world == 1)
             self.runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
         elif not a.no_graph:
             from nf_distillation_amd.training import CapturedStep
-            self.runner = CapturedStep(self.step, data[0], strict=True)
+            self.runner = CapturedStep(self.step, data[0], strict=self.world == 1)
             self.runner.prepare()  # eager warm-up + capture, before the W warm-up steps
-        if not a.no_graph and getattr(self.runner, "graph", None) is None:
+        # one rank: a step that was not captured is a failed run.  Several ranks (RCCL beside hipGraph capture has never run
+        # in this repo's tests): fall back to eager launches and SAY so in config.schedule rather than produce no number
+        if self.world == 1 and not a.no_graph and getattr(self.runner, "graph", None) is None:
             print("bench.py: the step was not captured into a hipGraph", file=sys.stderr)
             raise SystemExit(4)
 

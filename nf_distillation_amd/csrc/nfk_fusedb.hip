@@ -184,26 +184,48 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   }
   __syncthreads();
   stamp(1);
-  // im2col of g_a3 on the h-region (bf16 pairs); k = tap * Cout + co, the order of wd3's columns
+  // im2col of g_a3 on the h-region (bf16 pairs); k = tap * Cout + co, the order of wd3's columns.  As in the fused forward
+  // (nfk_fused2.hip): thread item = (pixel, tap, group of 4 channels), four items per thread with all four 16-byte LDS
+  // reads before the first write; taps outside the image read the zero slot.  Cout is even: a group holds 4 or 2 channels.
   {
     const int npad = (g.K3p - g.K3) >> 1;   // zero pairs behind the last tap (K3 = 9 * Cout is even)
-    for (int t = tid; t < MT32 * 32 * 10; t += 256) {
-      const int ph = (int)__umulhi((unsigned)t, 429496730u), tap = t - ph * 10;
-      char* dst = X3 + ph * g.X3S;
-      if (tap == 9) {
-        unsigned* d = reinterpret_cast<unsigned*>(dst + g.K3 * 2);
-        for (int e = 0; e < npad; ++e) d[e] = 0u;
-        continue;
+    for (int t = tid; t < MT32 * 32 * npad; t += 256) {
+      const int ph = (int)__umulhi((unsigned)t, 0xFFFFFFFFu / (unsigned)npad + 1u), e = t - ph * npad;
+      reinterpret_cast<unsigned*>(X3 + ph * g.X3S + g.K3 * 2)[e] = 0u;
+    }
+    const int G = (Cout + 3) >> 2, per_ph = 9 * G, nitems = MT32 * 32 * per_ph;
+    const unsigned mPP = 0xFFFFFFFFu / (unsigned)per_ph + 1u, mGG = 0xFFFFFFFFu / (unsigned)G + 1u;
+    const float* zslot = reinterpret_cast<const float*>(smem_fb + g.oZero);
+    const bool al16 = (Cout & 3) == 0;   // a pixel's channels start on a 16-byte boundary
+    for (int base = tid; base < nitems; base += 4 * 256) {
+      f32x4 v[4];
+      unsigned* d[4];
+      int np[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = min(base + u * 256, nitems - 1);
+        const int ph = (int)__umulhi((unsigned)t, mPP), r = t - ph * per_ph;
+        const int tap = (int)__umulhi((unsigned)r, mGG), c0 = (r - tap * G) * 4;
+        const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
+        const int rr = rem >> lw, xx = rem & (W - 1);
+        const int t3 = (tap * 11) >> 5;               // tap / 3 for tap < 9
+        const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+        const int rz = rr + halo + dy, xn = xx + dx;  // G3 has `zh` halo rows, the h-region `halo`
+        const bool ok = ph < g.P_h && (unsigned)rz < (unsigned)g.RZ && (unsigned)xn < (unsigned)W;
+        const float* src = ok ? G3 + ((sm * g.RZ + rz) * W + xn) * Cout + c0 : zslot;
+        if (al16) v[u] = *reinterpret_cast<const f32x4*>(src);
+        else {   // Cout % 4 == 2: 8-byte aligned pieces (the second one may belong to the next pixel: not written below)
+          const f32x2 lo = *reinterpret_cast<const f32x2*>(src), hi2 = *reinterpret_cast<const f32x2*>(src + 2);
+          v[u] = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+        }
+        d[u] = reinterpret_cast<unsigned*>(X3 + ph * g.X3S + (tap * Cout + c0) * 2);
+        np[u] = (base + u * 256 < nitems) ? ((c0 + 2 < Cout) ? 2 : 1) : 0;
       }
-      const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
-      const int rr = rem >> lw, xx = rem & (W - 1);
-      const int t3 = (tap * 11) >> 5;               // tap / 3 for tap < 9
-      const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
-      const int rz = rr + halo + dy, xn = xx + dx;  // G3 has `zh` halo rows, the h-region `halo`
-      const bool ok = ph < g.P_h && (unsigned)rz < (unsigned)g.RZ && (unsigned)xn < (unsigned)W;
-      const float* src = G3 + ((sm * g.RZ + rz) * W + xn) * Cout;
-      unsigned* d = reinterpret_cast<unsigned*>(dst + tap * Cout * 2);
-      for (int ci = 0; ci < Cout; ci += 2) d[ci >> 1] = ok ? fb_pack(src[ci], src[ci + 1]) : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (np[u] > 0) d[u][0] = fb_pack(v[u][0], v[u][1]);
+        if (np[u] > 1) d[u][1] = fb_pack(v[u][2], v[u][3]);
+      }
     }
   }
   __syncthreads();
