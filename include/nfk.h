@@ -412,7 +412,8 @@ enum { NFK_TUNE_F32_TILES = 0,               /* fp32 wide conv: 0 default, 1..5 
        NFK_TUNE_WGRAD_WIDE_MAX_SPLITS = 4,   /* cap for the 512x512 weight gradient */
        NFK_TUNE_NARROW_HALO_DGRAD = 5,       /* 1/0: conv1's dgrad through the halo-tile kernel / the split-K GEMM */
        NFK_TUNE_WGRAD_HALO = 6,              /* 1/0: conv3's weight gradient through the halo-tile kernel / the generic one */
-       NFK_TUNE_WGRAD_HALO_MAX_SPLITS = 7 };
+       NFK_TUNE_WGRAD_HALO_MAX_SPLITS = 7,
+       NFK_TUNE_RUN_HALF_TILES = 8 };        /* 1/0: runs of steps on tiny images use 32-pixel tiles when the grid is small */
 void nfk_tune(int knob, int value);
 void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
 

@@ -123,13 +123,18 @@ __device__ __forceinline__ int f2_h1_off(int px, int slot) {
 // tail, and a level costs one launch instead of K (the teacher's levels 2 / 3: 64 launches -> 2).  Per-step descriptors
 // (nfk_step2d) are read from a device array with scalar loads; per-step activation buffers are base + k * stride.
 // The arithmetic of every step is the single-step kernel's, instruction for instruction: results are bit-identical.
-template <int MT32, int NT3, int K1M, int NS, bool MULTI>
+// MO: output pixels per tile in units of 16 -- 4 (64 pixels, the default) or, for runs of steps on tiny images (CIFAR level
+// 3: 4x4 images, 16 tiles of 64 pixels at B = 64), 2: tiles of 32 pixels = two images, twice the workgroups, each with half
+// the mix / im2col / epilogue / tail work and half the MFMAs; only the weight stream per workgroup stays.
+template <int MT32, int NT3, int K1M, int NS, bool MULTI, int MO = 4>
 __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   static_assert(!MULTI || NS == 1, "a run of steps has no hidden split");
+  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MULTI && MT32 == 1), "small tiles: runs of steps on whole tiny images only");
+  constexpr int NPX = 16 * MO;   // output pixels of a tile
   typedef const __attribute__((address_space(4))) nfk_step2d CStep;   // scalar (constant-memory) loads of a descriptor
 #define F2S(p, f) (MULTI ? (p)->f : a.c.s.f)
   constexpr int HID = 512;
-  constexpr int MT_O = 4;   // 64 output pixels = 4 tiles of 16 (conv3 uses 16x16x32)
+  constexpr int MT_O = MO;  // output pixels = MO tiles of 16 (conv3 uses 16x16x32)
   extern __shared__ __attribute__((aligned(16))) char smem_f2[];
   const nfk_step2d& s = a.c.s;   // dimensions (the same for every step of a run); per-step POINTERS go through F2S
   // registers that live from one step of a run to the next: the per-channel parameters of the NEXT step, requested
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   // raw x rows of the tile (+halo), staged in the h1 region, which is free at that time.  In a run of steps the same
   // place receives the step's OUTPUT tile (= the next step's x) from the coupling tail, while the front of the region
   // still holds the cross-wave sums the tail reads (R3): it then starts behind those.
-  float* Xraw = reinterpret_cast<float*>(H1 + (MULTI ? 4 * 64 * NP * 4 : 0));
+  float* Xraw = reinterpret_cast<float*>(H1 + (MULTI ? 4 * NPX * NP * 4 : 0));
   // per-channel parameters of a step: global -> registers (load_params) -> LDS (store_params).  A run of steps loads
   // the NEXT step's before the current step's tail and stores them behind it.
   auto load_params = [&](CStep* p) {
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     // the Q operand of conv1's weight gradient -- a plain pixel-major GEMM operand instead of a 9-tap gather from z
     __bf16* x1g = reinterpret_cast<__bf16*>(c_masksave + (long)2 * s.B * HW * (HID / 8));
     constexpr int PPR = K1M * 2;   // 16-byte pieces per row
-    for (int p = tid; p < 64 * PPR; p += 256) {
+    for (int p = tid; p < NPX * PPR; p += 256) {
       const int po = p / PPR, slot = p % PPR;
       const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
       const int b = b0 + sm;
@@ -407,7 +412,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   auto save_rows = [&](__bf16* dstg, int col0, const char* img, int slots_log2, int slot0, unsigned char* mask) {
     const int spr = 1 << slots_log2;                 // 16-byte slots per row
     const int slot = tid & (spr - 1);
-    for (int po = tid >> slots_log2; po < 64; po += (256 >> slots_log2)) {
+    for (int po = tid >> slots_log2; po < NPX; po += (256 >> slots_log2)) {
       const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
       const int b = b0 + sm;
       if (b >= s.B) continue;
@@ -672,7 +677,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   for (int nt = 0; nt < NT3; ++nt)
 #pragma unroll
     for (int mo = 0; mo < MT_O; ++mo)
-      *reinterpret_cast<f32x4*>(R3 + ((wid * 64 + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc3[nt][mo];
+      *reinterpret_cast<f32x4*>(R3 + ((wid * NPX + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc3[nt][mo];
   const bool more = MULTI && st + 1 < nst;
   if (more) {
     // a run of steps: the next step's parameters are requested here and travel under the tail
@@ -684,13 +689,13 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     // partial conv3 sums of this workgroup's chunks -> slab qs; bias, scale and the coupling tail follow in
     // coupling_fwd_kernel once all NS slabs are there
     float* slab = a.c.ws + (long)qs * s.B * HW * Cout;
-    for (int idx = tid; idx < 64 * Cout; idx += 256) {
+    for (int idx = tid; idx < NPX * Cout; idx += 256) {
       const int po = (int)__umulhi((unsigned)idx, 0xFFFFFFFFu / (unsigned)Cout + 1u), n = idx - po * Cout;
       const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
       const int b = b0 + sm;
       if (b >= s.B) continue;
       const float* p = R3 + po * NP + n;
-      slab[((long)b * HW + (row0 + rr) * W + xx) * Cout + n] = (p[0] + p[64 * NP]) + (p[2 * 64 * NP] + p[3 * 64 * NP]);
+      slab[((long)b * HW + (row0 + rr) * W + xx) * Cout + n] = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
     }
     stamp(5);
     return;
@@ -706,7 +711,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   const float dld0 = F2S(sp, dld)[0];
   float* LS = reinterpret_cast<float*>(X1);
   float ls = 0.f;
-  for (int idx = tid; idx < 64 * C2h; idx += 256) {
+  for (int idx = tid; idx < NPX * C2h; idx += 256) {
     const int po = (int)__umulhi((unsigned)idx, mC2h), j = (idx - po * C2h) * 2;
     const int sm = po >> lrw, pl = po & ((1 << lrw) - 1), rr = pl >> lw, xx = pl & (W - 1);
     const int b = b0 + sm;
@@ -719,13 +724,13 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
       if (s.additive) {
         const float* p = R3 + po * NP + j;
         auto ld2 = [](const float* q) { return *reinterpret_cast<const f32x2t*>(q); };
-        const f32x2t h = ((ld2(p) + ld2(p + 64 * NP)) + (ld2(p + 2 * 64 * NP) + ld2(p + 3 * 64 * NP)) + ld2(Pb3 + j)) * ld2(Pe3 + j);
+        const f32x2t h = ((ld2(p) + ld2(p + NPX * NP)) + (ld2(p + 2 * NPX * NP) + ld2(p + 3 * NPX * NP)) + ld2(Pb3 + j)) * ld2(Pe3 + j);
         if (c_hsave) *reinterpret_cast<f32x2t*>(c_hsave + m * Cout + j) = h;
         out = z2 + h;
       } else {
         const float* p = R3 + po * NP + 2 * j;   // (shift, scale) of channel j, then of channel j + 1
         auto ld4 = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
-        const f32x4 h = ((ld4(p) + ld4(p + 64 * NP)) + (ld4(p + 2 * 64 * NP) + ld4(p + 3 * 64 * NP)) + ld4(Pb3 + 2 * j)) * ld4(Pe3 + 2 * j);
+        const f32x4 h = ((ld4(p) + ld4(p + NPX * NP)) + (ld4(p + 2 * NPX * NP) + ld4(p + 3 * NPX * NP)) + ld4(Pb3 + 2 * j)) * ld4(Pe3 + 2 * j);
         if (c_hsave) *reinterpret_cast<f32x4*>(c_hsave + m * Cout + 2 * j) = h;
         float s0, s1, l0, l1;
         f2_sigmoid_logsigmoid(h[1] + 2.f, s0, l0);
@@ -739,7 +744,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
     if (TS == 1) ls += lsp;
     else LS[idx] = lsp;
   }
-  for (int idx = tid; idx < 64 * Chh; idx += 256) {   // z1 passes through
+  for (int idx = tid; idx < NPX * Chh; idx += 256) {   // z1 passes through
     const int po = (int)__umulhi((unsigned)idx, mChh), j = (idx - po * Chh) * 2;
     const int sm = po >> lrw, pl = po & ((1 << lrw) - 1), rr = pl >> lw, xx = pl & (W - 1);
     const int b = b0 + sm;
@@ -800,16 +805,16 @@ static bool f2_pick(const nfk_step2d& s, F2Args* a) {
   return true;
 }
 
-template <int MT32, int NT3, int K1M, int NS, bool MULTI = false>
+template <int MT32, int NT3, int K1M, int NS, bool MULTI = false, int MO = 4>
 static int f2_launch_t(const F2Args& a, const F2Geom& g, int grid, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_step_fwd_kernel<MT32, NT3, K1M, NS, MULTI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_step_fwd_kernel<MT32, NT3, K1M, NS, MULTI, MO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
       return NFK_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((fused2_step_fwd_kernel<MT32, NT3, K1M, NS, MULTI>), dim3(grid * NS), dim3(256), g.total, st, a);
+  hipLaunchKernelGGL((fused2_step_fwd_kernel<MT32, NT3, K1M, NS, MULTI, MO>), dim3(grid * NS), dim3(256), g.total, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
@@ -871,6 +876,9 @@ int fused2_launch(const FusedCall& c, hipStream_t st) {
   return launch_coupling_fwd(cp, s.B, st);
 }
 
+static int g_run_half_tiles = 1;   // experiment knob (nfk_tune NFK_TUNE_RUN_HALF_TILES)
+void fused2_set_half_tiles(int on) { g_run_half_tiles = on; }
+
 // a run of steps in one launch: tiles must be whole images (no halo rows) and the next-x tile must fit behind R3
 static bool f2_run_ok(const nfk_step2d& s, F2Args* a, F2Geom* gp) {
   if (!f2_pick(s, a) || a->halo != 0) return false;
@@ -895,6 +903,23 @@ int fused2_run_launch(const nfk_fused_run& r, const nfk_step2d& first, unsigned 
   if (!f2_run_ok(first, &a, &g)) return NFK_ERR_ARG;
   a.c.s = first; a.c.x = r.x; a.c.ldx = r.ldx; a.c.stamps = stamps;
   a.run = r;
+  // Tiny images on a small grid (CIFAR level 3 at B = 64: 16 tiles of four 4x4 images): 32-pixel tiles instead -- twice the
+  // workgroups, each with half of everything but the weight stream.  Same arithmetic per pixel and per sample: bit-identical.
+  const int HW = first.H * first.W;
+  if (g_run_half_tiles && HW <= 16 && f2_grid(first, a) < 64 && g.NT3 == 3 && g.K1M == 16) {
+    F2Args h = a;
+    // 1 (default): 16-pixel tiles (one 4x4 image per workgroup) when even 32-pixel tiles would leave fewer than 64
+    // workgroups, else 32-pixel tiles; 2 / 3: always 16 / 32 (experiments)
+    const int npx = (HW == 16 && g_run_half_tiles != 3 && (g_run_half_tiles == 2 || f2_grid(first, a) < 32)) ? 16 : 32;
+    h.TS = npx / HW;
+    h.lrw = ilog2_exact(h.R * first.W);
+    h.lhw = ilog2_exact((h.R + 2 * h.halo) * first.W);
+    const F2Geom gh = f2_geom(first, h.R, h.TS, h.halo);
+    const bool fits = gh.MT32 == 1 && gh.total <= 160 * 1024 - 512 &&
+                      (size_t)4 * npx * gh.NT3 * 16 * 4 + (size_t)h.TS * gh.RZ * first.W * first.C * 4 <= (size_t)gh.MT32 * 32 * 1024;
+    if (fits && npx == 32) return f2_launch_t<1, 3, 16, 1, true, 2>(h, gh, (first.B + h.TS - 1) / h.TS, st);
+    if (fits && npx == 16) return f2_launch_t<1, 3, 16, 1, true, 1>(h, gh, first.B, st);
+  }
   return f2_dispatch<2, 1, true>(a, g, f2_grid(first, a), st);
 }
 
