@@ -120,7 +120,7 @@ void nfk_tune(int knob, int value) {
     case NFK_TUNE_NARROW_HALO_DGRAD: set_tuning_bf16(2900 + (value & 1)); break;
     case NFK_TUNE_WGRAD_HALO: set_tuning_bf16(2910 + (value & 1)); break;
     case NFK_TUNE_WGRAD_HALO_MAX_SPLITS: set_tuning_bf16(3000 + value); break;
-    case NFK_TUNE_RUN_HALF_TILES: fused2_set_half_tiles(value); break;
+    case NFK_TUNE_RUN_HALF_TILES: fused2_set_half_tiles(value); fusedb_set_small_tiles(value); break;
     default: break;
   }
 }

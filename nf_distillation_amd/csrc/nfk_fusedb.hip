@@ -83,10 +83,14 @@ __device__ __forceinline__ int fb_img_off(int px, int slot) {
   return px * 1024 + ((((slot ^ px) & 15) | (slot & ~15)) << 4);
 }
 
-template <int MT32, int NTD, int K3M>
+// MO: output pixels per tile in units of 16 -- 4 (64 pixels) or, on tiny images with a small grid (CIFAR level 3), 2 / 1:
+// more workgroups, each with a smaller share of everything but the weight stream (as nfk_fused2.hip's runs of steps).
+template <int MT32, int NTD, int K3M, int MO = 4>
 __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
+  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MT32 == 1), "small tiles: whole tiny images only");
   constexpr int HID = 512;
-  constexpr int MT_O = 4;   // 64 output pixels = 4 tiles of 16 (dgrad1 uses 16x16x32)
+  constexpr int NPX = 16 * MO;   // output pixels of a tile
+  constexpr int MT_O = MO;       // output m-tiles of 16 (dgrad1 uses 16x16x32)
   extern __shared__ __attribute__((aligned(16))) char smem_fb[];
   const nfk_step2d& s = a.c.s;
   const int W = s.W, H = s.H, Ch = s.C / 2, Cout = s.Cout, HW = H * W;
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   // row's 64 pieces by consecutive threads
   auto save_rows = [&](__bf16* dstg) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < NPX / 4; ++it) {
       const int p = tid + 256 * it, po = p >> 6, slot = p & 63;
       const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
       const int b = b0 + sm;
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     // h2[m][ci]) -- instead of nine shifted passes over the 512-wide h2
     __bf16* x3g = reinterpret_cast<__bf16*>(a.c.x3save);
     constexpr int PPR = K3M * 2;   // 16-byte pieces per row
-    for (int p = tid; p < 64 * PPR; p += 256) {
+    for (int p = tid; p < NPX * PPR; p += 256) {
       const int po = p / PPR, slot = p % PPR;
       const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
       const int b = b0 + sm;
@@ -463,16 +467,16 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   for (int nt = 0; nt < NTD; ++nt)
 #pragma unroll
     for (int mo = 0; mo < MT_O; ++mo)
-      *reinterpret_cast<f32x4*>(R3 + ((wid * 64 + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc1[nt][mo];
+      *reinterpret_cast<f32x4*>(R3 + ((wid * NPX + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc1[nt][mo];
   __syncthreads();
   const unsigned mCh = 0xFFFFFFFFu / (unsigned)Ch + 1u;
-  for (int idx = tid; idx < 64 * Ch; idx += 256) {
+  for (int idx = tid; idx < NPX * Ch; idx += 256) {
     const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
     const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
     const int b = b0 + sm;
     if (b >= s.B) continue;
     const float* p = R3 + po * NP + n;
-    a.c.d1[((long)b * HW + (row0 + rr) * W + xx) * Ch + n] = (p[0] + p[64 * NP]) + (p[2 * 64 * NP] + p[3 * 64 * NP]);
+    a.c.d1[((long)b * HW + (row0 + rr) * W + xx) * Ch + n] = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
   }
   stamp(10);
 }
@@ -510,19 +514,22 @@ static bool fb_pick(const nfk_step2d& s, FBArgs* a) {
          (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4);
 }
 
-template <int MT32, int NTD, int K3M>
+template <int MT32, int NTD, int K3M, int MO = 4>
 static int fb_launch_t(const FBArgs& a, const FBGeom& g, int grid, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusedb_step_bwd_kernel<MT32, NTD, K3M>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusedb_step_bwd_kernel<MT32, NTD, K3M, MO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
       return NFK_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((fusedb_step_bwd_kernel<MT32, NTD, K3M>), dim3(grid), dim3(256), g.total, st, a);
+  hipLaunchKernelGGL((fusedb_step_bwd_kernel<MT32, NTD, K3M, MO>), dim3(grid), dim3(256), g.total, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
+
+static int g_small_tiles = 1;   // experiment knob (shared with the forward: nfk_tune NFK_TUNE_RUN_HALF_TILES)
+void fusedb_set_small_tiles(int on) { g_small_tiles = on; }
 
 int fusedb_grid(const nfk_step2d& s) {
   FBArgs a{};
@@ -544,6 +551,21 @@ int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
   prof_scope_begin(cls, 2.0 * M * (512.0 * 9 * s.Cout + 512.0 * 512 + 9.0 * 512 * (s.C / 2)),
                    M * (4.0 * s.Cout + 4.0 * (s.C / 2) + 2 * 512 * 2.0 + 2 * 64.0) + 2.0 * 512 * (9.0 * s.Cout + 512 + 9.0 * (s.C / 2)), st);
   int rc = NFK_ERR_ARG;
+  // 4x4 images on a small grid (CIFAR level 3 at B = 64: 16 tiles): 16- / 32-pixel tiles, 64 / 32 workgroups
+  const int HW = s.H * s.W;
+  if (g_small_tiles && HW == 16 && a.halo == 0 && grid < 64 && g.NTD == 2 && g.K3M == 28) {
+    FBArgs h = a;
+    const int npx = grid < 32 ? 16 : 32;
+    h.TS = npx / HW;
+    h.lrw = fb_ilog2_exact(h.R * s.W);
+    h.lhw = fb_ilog2_exact(h.R * s.W);
+    const FBGeom gh = fb_geom(s, h.R, h.TS, h.halo);
+    if (gh.MT32 == 1 && gh.total <= 160 * 1024 - 512 && (size_t)4 * npx * gh.NTD * 16 * 4 <= (size_t)32 * 1024) {
+      rc = npx == 16 ? fb_launch_t<1, 2, 28, 1>(h, gh, s.B, st) : fb_launch_t<1, 2, 28, 2>(h, gh, (s.B + h.TS - 1) / h.TS, st);
+      prof_scope_end(cls, st);
+      return rc;
+    }
+  }
   if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<3, 1, 8>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) rc = fb_launch_t<3, 1, 4>(a, g, grid, st);
   else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<2, 1, 8>(a, g, grid, st);

@@ -152,6 +152,7 @@ int triple_wgrad_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, 
 void triple_wgrad_debug_skip(int mask);
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 void fused2_set_half_tiles(int on);
+void fusedb_set_small_tiles(int on);
 int fused2_launch(const FusedCall& c, hipStream_t st);
 size_t fused2_ws_floats(const nfk_step2d& s);
 
