@@ -207,10 +207,10 @@ def lib():
 
 PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2> (64x64)",
                 "conv_gemm_kernel<*,2,1,4> (narrow-N)", "wgrad_kernel<4,4,2,2>", "wgrad_kernel<*,2,1,4>",
-                "fused2_step_fwd_kernel<*,1,*> (FlowStep forward, Cout <= 16: CIFAR level 1 = <3,1,4,1,false>)",
-                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8,1,true>: one launch per "
+                "fused2_step_fwd_kernel<*,1,*> (FlowStep forward, Cout <= 16: CIFAR level 1 = <3,1,4,1,false,4>)",
+                "fused2_step_fwd_kernel<*,2,*> (FlowStep forward, Cout <= 32: CIFAR level 2 = <2,2,8,1,true,4>: one launch per "
                 "run of steps, flops and bytes of the whole run)",
-                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <2,3,16,1,true>: one launch per "
+                "fused2_step_fwd_kernel<*,3,*> (FlowStep forward, Cout <= 48: CIFAR level 3 = <1,3,16,1,true,1>, 16-pixel tiles: one launch per "
                 "run of steps, flops and bytes of the whole run)",
                 ) + tuple(f"dual_dgrad_wgrad_bf16_kernel {conv}, {lvl}"
                           for conv in ("conv3 (block.4: wide dgrad + narrow wgrad)", "conv2 (block.2: 512x512)",
@@ -223,12 +223,12 @@ PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2
 
 # class -> rocprofv3 symbol of the instance the student's chain launches at CIFAR B=64 (tools/pmc_traffic.py, bench.py `traffic`)
 PROF_SYMBOLS = {
-    PROF_CLASSES[5]: "nfk::fused2_step_fwd_kernel<3, 1, 4, 1, false>",
-    PROF_CLASSES[6]: "nfk::fused2_step_fwd_kernel<2, 2, 8, 1, true>",
-    PROF_CLASSES[7]: "nfk::fused2_step_fwd_kernel<2, 3, 16, 1, true>",
-    PROF_CLASSES[17]: "nfk::fusedb_step_bwd_kernel<3, 1, 8>",
-    PROF_CLASSES[18]: "nfk::fusedb_step_bwd_kernel<2, 1, 16>",
-    PROF_CLASSES[19]: "nfk::fusedb_step_bwd_kernel<2, 2, 28>",
+    PROF_CLASSES[5]: "nfk::fused2_step_fwd_kernel<3, 1, 4, 1, false, 4>",
+    PROF_CLASSES[6]: "nfk::fused2_step_fwd_kernel<2, 2, 8, 1, true, 4>",
+    PROF_CLASSES[7]: "nfk::fused2_step_fwd_kernel<1, 3, 16, 1, true, 1>",
+    PROF_CLASSES[17]: "nfk::fusedb_step_bwd_kernel<3, 1, 8, 4>",
+    PROF_CLASSES[18]: "nfk::fusedb_step_bwd_kernel<2, 1, 16, 4>",
+    PROF_CLASSES[19]: "nfk::fusedb_step_bwd_kernel<1, 2, 28, 1>",
 }
 
 
