@@ -124,6 +124,8 @@ class Leg:
             # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py)
             from nf_distillation_amd.pipeline import PipelinedStep
             self.runner = PipelinedStep(self.step, data[0], strict=self.world == 1)
+            if getattr(a, "teacher_start_layer", None) is not None:   # experiment knob (-1: fork at the start of the call)
+                self.runner.teacher_starts_after_layer = None if a.teacher_start_layer < 0 else a.teacher_start_layer
             self.runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
         elif not a.no_graph:
             from nf_distillation_amd.training import CapturedStep
@@ -267,6 +269,8 @@ def main():
     ap.add_argument("--fused-runs", choices=("both", "teacher", "student", "off"), default=None,
                     help="experiment knob: which model walks a whole level's FlowSteps in ONE launch (levels 2 / 3; "
                          "default: the engines' default)")
+    ap.add_argument("--teacher-start-layer", type=int, default=None,
+                    help="experiment knob: student layer after which the pipelined teacher branch is forked (-1: at once)")
     ap.add_argument("--tune", type=int, nargs="*", default=None, metavar="KNOB VALUE",
                     help="experiment knobs: pairs for nfk_tune(knob, value) (include/nfk.h NFK_TUNE_*)")
     ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_step2d_grads.bwd_mode of the student "

@@ -62,6 +62,11 @@ class PipelinedStep:
         # of spreading over 256 for 19.8 + 5 us (split + finishing launch); +2 % step throughput.  Alone on the chip (the
         # sequential schedule) the 4-way split of both levels is the faster one and stays the engine's default.
         self.student_split = "frugal"
+        # the student layer after which the teacher's branch is forked; None (default): at the start of the call.  Measured
+        # (bench.py --teacher-start-layer): forking it after the student's first level, so that the two chains' full-chip
+        # level-1 launches do not meet, LOSES 2.6 % (after the second level: 7.5 %) -- the teacher's chain then ends later
+        # than the student's backward can use the freed CUs
+        self.teacher_starts_after_layer = None
 
     # ------------------------------------------------------------------ the two branches
     def _teacher_branch(self):
@@ -111,15 +116,31 @@ class PipelinedStep:
         """both branches up to the end of the backward"""
         main = torch.cuda.current_stream()
         self._handover()   # what the previous call prepared
-        fork = torch.cuda.Event()
-        fork.record(main)
-        self.side.wait_event(fork)
-        with torch.cuda.stream(self.side):
-            self._teacher_branch()
-            join = torch.cuda.Event()
-            join.record(self.side)
-        out = self._student_fwd_bwd()
-        main.wait_event(join)
+        box = {}
+
+        def start_teacher():
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self.side.wait_event(fork)
+            with torch.cuda.stream(self.side):
+                self._teacher_branch()
+                box["join"] = torch.cuda.Event()
+                box["join"].record(self.side)
+
+        seng = self.step.student.flow.engine() if hasattr(self.step.student, "flow") else None
+        k = self.teacher_starts_after_layer
+        if seng is None or k is None:
+            start_teacher()
+            out = self._student_fwd_bwd()
+        else:
+            seng.layer_hooks = {k: start_teacher}   # experiment: fork the teacher once student layer k has been enqueued
+            try:
+                out = self._student_fwd_bwd()
+            finally:
+                seng.layer_hooks = {}
+            if "join" not in box:
+                start_teacher()
+        main.wait_event(box["join"])
         return out
 
     def _body(self):
