@@ -439,7 +439,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int c0, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TN, int TM, int WN, int WM>
+// PLAIN: both operands are bf16, pixel-major, without taps and 16-byte loadable (the fused backward's three GEMMs): the
+// per-load index arithmetic of the general case -- two integer divisions per Q piece for the tap geometry, element-wise
+// fallbacks -- drops out at compile time (it sat in front of every chunk's loads: ~300 VALU instructions per chunk and thread
+// beside 512 cycles of MFMA).
+template <int TN, int TM, int WN, int WM, bool PLAIN = false>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, const int S, const int z_in) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
   constexpr int SP = wg_stride(BI), SQ = wg_stride(BJ);
@@ -497,6 +501,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
       const int m = mb + p_pl[t];
       const bool ok = m < a.M && p_col[t] != OOB;
       const unsigned base = ((unsigned)m * (unsigned)a.ldp + p_col[t]) * pes;
+      if (PLAIN) { preg[t] = ld16(rP, ok ? base : OOB); continue; }
       if (pv) preg[t] = load8(rP, ok ? base : OOB, a.pbf16);
       else {
         u32x4b v = {0u, 0u, 0u, 0u};
@@ -512,6 +517,11 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
     for (int t = 0; t < QL; ++t) {
       const int idx = tid + 256 * t, g = idx % QG, j = j0 + g * 8;
       const int m = mb + q_pl[t];
+      if (PLAIN) {
+        const bool okq = idx < WPX * QG && m < a.M && j < a.J;
+        qreg[t] = ld16(rQ, okq ? ((unsigned)m * (unsigned)a.ldq + (unsigned)j) * 2u : OOB);
+        continue;
+      }
       const int rem = m % HW, y = rem / a.W, x = rem - y * a.W;
       const bool rowok = idx < WPX * QG && m < a.M;
       auto elem_off = [&](int jj, bool& ok) {
@@ -1002,11 +1012,11 @@ __global__ void __launch_bounds__(256) wgrad_tail_kernel(WgradArgs w2, int nb2, 
   b -= n_cm;
   if (b < an.nparts) { actnorm_sum_body(an, b); return; }
   b -= an.nparts;
-  if (b < nb2 * S2) { wgrad_bf16_body<4, 4, 2, 2>(w2, b % nb2, S2, b / nb2); return; }
+  if (b < nb2 * S2) { wgrad_bf16_body<4, 4, 2, 2, true>(w2, b % nb2, S2, b / nb2); return; }
   b -= nb2 * S2;
-  if (b < nb3 * S3) { wgrad_bf16_body<4, 4, 2, 2>(w3, b % nb3, S3, b / nb3); return; }
+  if (b < nb3 * S3) { wgrad_bf16_body<4, 4, 2, 2, true>(w3, b % nb3, S3, b / nb3); return; }
   b -= nb3 * S3;
-  if (b < nb1 * S1) { wgrad_bf16_body<4, 4, 2, 2>(w1, b % nb1, S1, b / nb1); return; }
+  if (b < nb1 * S1) { wgrad_bf16_body<4, 4, 2, 2, true>(w1, b % nb1, S1, b / nb1); return; }
   b -= nb1 * S1;
   step_tail_body(sg, tf, b);
 }
