@@ -104,6 +104,8 @@ typedef struct nfk_split2d {
   int32_t B, H, W, C;
   const float *bias, *es;           /* conv.bias [C], exp(3 logs) [C] (prep es3) */
   const float *wt, *wd;             /* repacked weights */
+  const float *w;                   /* conv.weight itself, [C][C/2][3][3]: read by the fused forward / backward (one launch each);
+                                     * NULL -> the generic GEMM path */
 } nfk_split2d;
 
 /* One 1-D (tabular) FlowStep: ActNorm1d + x @ W + get_block_1d MLP + coupling tail
@@ -152,6 +154,7 @@ size_t nfk_step2d_fwd_ws_floats(const nfk_step2d *s);   /* a3 slab workspace    
 size_t nfk_step2d_bwd_ws_floats(const nfk_step2d *s);
 size_t nfk_split2d_fwd_ws_floats(const nfk_split2d *s);
 size_t nfk_split2d_bwd_ws_floats(const nfk_split2d *s);
+int nfk_split2d_fused_ok(const nfk_split2d *s);   /* 1: nfk_split2d_fwd / _bwd take the one-launch path for this geometry */
 
 /* ---- parameter-side kernels ---------------------------------------------------------------- */
 /* descs: DEVICE array[nsteps].  One workgroup per step. */
@@ -413,7 +416,8 @@ enum { NFK_TUNE_F32_TILES = 0,               /* fp32 wide conv: 0 default, 1..5 
        NFK_TUNE_NARROW_HALO_DGRAD = 5,       /* 1/0: conv1's dgrad through the halo-tile kernel / the split-K GEMM */
        NFK_TUNE_WGRAD_HALO = 6,              /* 1/0: conv3's weight gradient through the halo-tile kernel / the generic one */
        NFK_TUNE_WGRAD_HALO_MAX_SPLITS = 7,
-       NFK_TUNE_RUN_HALF_TILES = 8 };        /* 1/0: runs of steps on tiny images use 32-pixel tiles when the grid is small */
+       NFK_TUNE_RUN_HALF_TILES = 8,          /* 1/0: runs of steps on tiny images use 32-pixel tiles when the grid is small */
+       NFK_TUNE_SPLIT_FUSED = 9 };           /* 1/0: Split2d forward / backward as one fused fp32 launch each (default 1) */
 void nfk_tune(int knob, int value);
 void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
 

@@ -75,7 +75,7 @@ class Step2dNext(C.Structure):
 
 class Split2d(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-                ("bias", c_fp), ("es", c_fp), ("wt", c_fp), ("wd", c_fp)]
+                ("bias", c_fp), ("es", c_fp), ("wt", c_fp), ("wd", c_fp), ("w", c_fp)]
 
 
 class TabStepC(C.Structure):
@@ -94,7 +94,7 @@ KD_MAX_PAIRS = 16   # NFK_KD_MAX_PAIRS
 BWD_DEFAULT, BWD_SEPARATE, BWD_DUAL_SMALL, BWD_DUAL, BWD_FUSED = 0, 1, 2, 3, 4
 # nfk_tune knobs
 (TUNE_F32_TILES, TUNE_BF16_BIG_TILE_MIN_K64, TUNE_WGRAD_MAX_SPLITS, TUNE_WGRAD_TARGET_WGS, TUNE_WGRAD_WIDE_MAX_SPLITS,
- TUNE_NARROW_HALO_DGRAD, TUNE_WGRAD_HALO, TUNE_WGRAD_HALO_MAX_SPLITS, TUNE_RUN_HALF_TILES) = range(9)
+ TUNE_NARROW_HALO_DGRAD, TUNE_WGRAD_HALO, TUNE_WGRAD_HALO_MAX_SPLITS, TUNE_RUN_HALF_TILES, TUNE_SPLIT_FUSED) = range(10)
 
 
 class KdPairs(C.Structure):
@@ -129,6 +129,7 @@ _PROTOS = {
     "nfk_step2d_bwd_ws_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_split2d_fwd_ws_floats": (u64, [C.POINTER(Split2d)]),
     "nfk_split2d_bwd_ws_floats": (u64, [C.POINTER(Split2d)]),
+    "nfk_split2d_fused_ok": (i32, [C.POINTER(Split2d)]),
     "nfk_prep": (i32, [vp, i32, i32, vp]),
     "nfk_prep_bwd": (i32, [vp, vp, i32, vp, i32, i32, vp]),
     "nfk_prep_inv_bwd": (i32, [vp, vp, i32, vp, i32, vp]),

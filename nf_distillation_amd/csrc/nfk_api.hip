@@ -85,6 +85,7 @@ struct nfk_aux {
   hipEvent_t ev[4];
   bool forked;   // work was sent to the auxiliary stream since the last join
 };
+static int g_split_fused = 1;                          // nfk_tune(NFK_TUNE_SPLIT_FUSED)
 static unsigned long long* g_bwd_stamps = nullptr;   // diagnostic (nfk_fused_bwd_set_stamps)
 static void fork_to_aux(nfk_aux* ax, hipStream_t main_st, int i) {
   ax->forked = true;
@@ -121,6 +122,7 @@ void nfk_tune(int knob, int value) {
     case NFK_TUNE_WGRAD_HALO: set_tuning_bf16(2910 + (value & 1)); break;
     case NFK_TUNE_WGRAD_HALO_MAX_SPLITS: set_tuning_bf16(3000 + value); break;
     case NFK_TUNE_RUN_HALF_TILES: fused2_set_half_tiles(value); fusedb_set_small_tiles(value); break;
+    case NFK_TUNE_SPLIT_FUSED: g_split_fused = value & 1; break;
     default: break;
   }
 }
@@ -140,16 +142,20 @@ size_t nfk_step2d_fwd_ws_floats(const nfk_step2d* s) {
   return align4((size_t)splitk_of(s->bf16, (int)M, s->Cout, 9 * s->hidden) * M * s->Cout);
 }
 size_t nfk_step2d_bwd_ws_floats(const nfk_step2d* s) { return step_bwd_layout(s).total; }
-size_t nfk_split2d_fwd_ws_floats(const nfk_split2d* s) {
-  const size_t M = (size_t)s->B * s->H * s->W;
+size_t nfk_split2d_fwd_ws_floats(const nfk_split2d* s) {   // (the inverse always takes the GEMM path; the fused forward
+  const size_t M = (size_t)s->B * s->H * s->W;             //  needs B * tiles-per-sample floats, far less)
   return align4((size_t)conv_splitk((int)M, s->C, 9 * (s->C / 2), EPI_RAW) * M * s->C);
 }
 size_t nfk_split2d_bwd_ws_floats(const nfk_split2d* s) {
   const size_t M = (size_t)s->B * s->H * s->W;
   const int Ch = s->C / 2;
-  return align4(M * s->C) + align4((size_t)conv_splitk((int)M, Ch, 9 * s->C, EPI_RAW) * M * Ch) +
-         align4((size_t)s->B * 2 * s->C) + align4((size_t)wgrad_splits((int)M, s->C, 9 * Ch) * s->C * 9 * Ch);
+  const size_t gemm = align4(M * s->C) + align4((size_t)conv_splitk((int)M, Ch, 9 * s->C, EPI_RAW) * M * Ch) +
+                      align4((size_t)s->B * 2 * s->C) + align4((size_t)wgrad_splits((int)M, s->C, 9 * Ch) * s->C * 9 * Ch);
+  const size_t nt = (size_t)split2d_fused_tiles(*s);
+  const size_t fused = align4(nt * 2 * s->C) + align4(nt * s->C * 9 * Ch);
+  return gemm > fused ? gemm : fused;
 }
+int nfk_split2d_fused_ok(const nfk_split2d* s) { return (s->w && g_split_fused && split2d_fused_tiles(*s) > 0) ? 1 : 0; }
 
 int nfk_prep(const nfk_prep_desc* descs, int nsteps, int want_inverse, void* stream) {
   return launch_prep(descs, nsteps, want_inverse, S_(stream));
@@ -565,6 +571,10 @@ int nfk_split2d_fwd(const nfk_split2d* s, const float* x, const float* ld_in, fl
                     float* ws, float* ld_out, void* stream) {
   hipStream_t st = S_(stream);
   const int M = s->B * s->H * s->W, Ch = s->C / 2;
+  if (nfk_split2d_fused_ok(s)) {   // conv + prior in one launch, then the per-sample sums of the tiles' partials
+    NFK_TRY(split2d_fused_fwd(*s, x, s->w, z1out, hsave, ws, st));
+    return ld_out ? nfk_ld_finish(ld_in, ws, 1, s->B, split2d_fused_tps(*s), ld_out, stream) : NFK_OK;
+  }
   ConvGemmArgs c = conv_args(x, s->C, s->B, s->H, s->W, Ch, 9, s->wt, s->C, ws, s->C, EPI_RAW);
   NFK_TRY(conv_gemm(c, st));
   SplitArgs a{};
@@ -590,6 +600,17 @@ int nfk_split2d_bwd(const nfk_split2d* s, const float* x, const float* hsave, co
                     float* ws, void* stream) {
   hipStream_t st = S_(stream);
   const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, M = B * H * W;
+  if (nfk_split2d_fused_ok(s)) {   // everything but the final reductions in one launch (nfk_split.hip)
+    const int nt = split2d_fused_tiles(*s);
+    float* part = ws;
+    float* slab = part + align4((size_t)nt * 2 * C);
+    NFK_TRY(split2d_fused_bwd(*s, x, hsave, s->w, g_z1, g_ext, g_ld, g_x, part, slab, st));
+    nfk_small_grad_args sg{};
+    sg.tail = part; sg.B = nt; sg.n3 = C; sg.g_bias3 = g_bias; sg.g_l3 = g_logs;
+    StepTailArgs f{};
+    f.slabs[0] = slab; f.gradW[0] = g_w; f.stride[0] = (long)C * 9 * Ch; f.S[0] = nt; f.Cout[0] = C; f.Cin[0] = Ch; f.taps[0] = 9;
+    return launch_step_tail(sg, f, st);
+  }
   const int Sd = conv_splitk(M, Ch, 9 * C, EPI_RAW), Sw = wgrad_splits(M, C, 9 * Ch);
   float* ga = ws;
   float* dslab = ga + align4((size_t)M * C);

@@ -202,6 +202,13 @@ int launch_split_inv(const SplitArgs& a, int B, hipStream_t st);
 int launch_split_bwd(const SplitBwdArgs& a, int B, hipStream_t st);
 int launch_add_slabs(const float* g, int ldg, const float* gext, int ldge, const float* slab, int S,
                      long slab_stride, float* out, int ldo, long M, int Ch, hipStream_t st);
+// nfk_split.hip: Split2d's conv + prior in one launch per direction (fp32, vector ALUs)
+int split2d_fused_tiles(const nfk_split2d& s);   // 0: geometry not covered
+int split2d_fused_tps(const nfk_split2d& s);
+int split2d_fused_fwd(const nfk_split2d& s, const float* x, const float* w, float* z1out, float* hsave, float* ldpart,
+                      hipStream_t st);
+int split2d_fused_bwd(const nfk_split2d& s, const float* x, const float* h, const float* w, const float* gz1, const float* gext,
+                      const float* gld, float* gx, float* part, float* wslab, hipStream_t st);
 int launch_prior_fwd(const PriorArgs& a, int B, hipStream_t st);
 int launch_prior_bwd(const PriorBwdArgs& a, int B, hipStream_t st);
 int launch_small_grads(const SmallGradArgs& a, hipStream_t st);

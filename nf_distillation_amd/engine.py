@@ -271,6 +271,7 @@ class FlowEngine:
                 cs.B, cs.H, cs.W, cs.C = B, r.H, r.W, r.C
                 cs.bias, cs.es = ptr(cz.conv.bias), pb + 4 * off["es3"]
                 cs.wt, cs.wd = kb + 4 * off["wt"], kb + 4 * off["wd"]
+                cs.w = ptr(cz.conv.weight)
                 r.cs = cs
                 rd = RepackDesc()
                 rd.w, rd.wt, rd.wd = ptr(cz.conv.weight), cs.wt, cs.wd
