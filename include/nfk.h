@@ -213,9 +213,18 @@ int nfk_prior_bwd(const float *z, int ldz, const float *prior, long prior_bstrid
  * backward (hsave may be NULL when no backward follows; z/h1/h2 may then be reused scratch). */
 int nfk_step2d_fwd(const nfk_step2d *s, const float *x, int ldx, const float *ld_in, float *z, float *h1,
                    float *h2, float *hsave, float *ws, float *zout, float *ld_out, void *stream);
-/* FlowStep.reverse_flow (models/flows.py:173-202): y -> x.  ld_* may be NULL. */
+/* FlowStep.reverse_flow (models/flows.py:173-202): y -> x.  ld_* may be NULL.  hsave: NULL, or [M][Cout] where the
+ * coupling net's (shift | scale-raw) output is kept for nfk_step2d_inv_bwd (z, h1, h2 must then be kept too). */
 int nfk_step2d_inv(const nfk_step2d *s, const float *y, int ldy, const float *ld_in, float *z, float *h1,
-                   float *h2, float *ws, float *xout, float *ld_out, void *stream);
+                   float *h2, float *hsave, float *ws, float *xout, float *ld_out, void *stream);
+/* backward of nfk_step2d_inv -- the reverse pass with gradients (pl_module.py:229-243 runs the student's reverse pass under
+ * autograd for the perceptual loss): g_xout = dL/dx, g_ld = dL/d(logdet_out) or NULL -> g_y [M][C] = dL/dy, the conv-net
+ * parameter gradients accumulated through `g` as in nfk_step2d_bwd, and the partial (g_Wi, g_ci) rows of the inverse channel
+ * mix in g->mix_part for nfk_prep_inv_bwd.  ws: nfk_step2d_bwd_ws_floats floats.  Plain launches on `stream` (this pass is
+ * not on the benchmark's path: no fused / merged kernels). */
+int nfk_step2d_inv_bwd(const nfk_step2d *s, const nfk_step2d_grads *g, const float *y, int ldy, const float *z,
+                       const float *h1, const float *h2, const float *hsave, const float *g_xout, const float *g_ld,
+                       float *g_y, float *ws, void *stream);
 /* backward of nfk_step2d_fwd: g_out (+ optional g_ext) and g_ld -> g_x, parameter grads. */
 int nfk_step2d_bwd(const nfk_step2d *s, const nfk_step2d_grads *g, const float *x, int ldx, const float *z,
                    const float *h1, const float *h2, const float *hsave, const float *g_out,

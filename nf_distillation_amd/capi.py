@@ -147,7 +147,8 @@ _PROTOS = {
     "nfk_prior_fwd": (i32, [vp, i32, vp, lng, vp, vp, vp, i32, i32, i32, f32, vp]),
     "nfk_prior_bwd": (i32, [vp, i32, vp, lng, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nfk_step2d_fwd": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "nfk_step2d_inv": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_step2d_inv": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nfk_step2d_inv_bwd": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nfk_step2d_bwd": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp,
                              vp, vp]),
     "nfk_step2d_bwd_deferred": (i32, [C.POINTER(Step2d), C.POINTER(Step2dGrads), vp, i32, vp, vp, vp, vp, vp, vp, vp,

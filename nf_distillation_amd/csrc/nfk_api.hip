@@ -16,7 +16,8 @@ int splitk_of(int bf16, int M, int N, int K);
 
 struct StepBwdWs {
   size_t ga3, gz, ga2, ga1, d1slab, col2, col1, tail, wslab, x3, total;
-  int S1, S3w, S2w, S1w, mb1, mb2;
+  int S1, S3w, S2w, S1w, mb1, mb2;   // mb1 / mb2: rows RESERVED for the column-sum partials (max over the paths)
+  int mb1g, mb2g;                     // rows the plain dgrad GEMMs' epilogues write
   // fused backward: conv3's / conv1's weight gradients as plain GEMMs on the im2col rows the fused kernels leave
   // (P = x3 [M][K3p] from nfk_fusedb.hip, Q = x1 [M][K1p] from nfk_fused2.hip): their split counts and row lengths
   int S3f, S1f, K3p, K1p;
@@ -33,6 +34,7 @@ StepBwdWs step_bwd_layout(const nfk_step2d* s) {
   // column-sum partials of the two dgrad epilogues: one row pair per m-block of THAT launch's tiling
   w.mb2 = s->bf16 ? conv_mblocks_bf16((int)M, hid, 9 * s->Cout) : conv_mblocks((int)M, hid);   // conv3 dgrad -> col2
   w.mb1 = s->bf16 ? conv_mblocks_bf16((int)M, hid, hid) : conv_mblocks((int)M, hid);           // conv2 dgrad -> col1
+  w.mb1g = w.mb1; w.mb2g = w.mb2;
   const bool fused = s->bf16 && fusedb_grid(*s) > 0;
   const int fg = fused ? actnorm_sum_parts((int)M) : 0;   // the fused backward's partial rows
   if (fg > w.mb2) w.mb2 = fg;
@@ -276,17 +278,74 @@ int nfk_step2d_fwd(const nfk_step2d* s, const float* x, int ldx, const float* ld
 }
 
 int nfk_step2d_inv(const nfk_step2d* s, const float* y, int ldy, const float* ld_in, float* z, float* h1,
-                   float* h2, float* ws, float* xout, float* ld_out, void* stream) {
+                   float* h2, float* hsave, float* ws, float* xout, float* ld_out, void* stream) {
   hipStream_t st = S_(stream);
   const int M = s->B * s->H * s->W, HW = s->H * s->W;
   if (!s->Wi || !s->ci) return NFK_ERR_ARG;
   NFK_TRY(coupling_net_fwd(s, y, ldy, h1, h2, ws, st));
   const int S = splitk_of(s->bf16, M, s->Cout, 9 * s->hidden);
-  NFK_TRY(nfk_coupling_inv(ws, S, s->bias3, s->es3, y, ldy, z, s->C, ld_in, s->dld, ld_out, s->B, HW, s->C,
-                           s->Cout, s->additive, stream));
+  CouplingArgs a{};
+  a.a3 = ws; a.S = S; a.slab_stride = (long)M * s->Cout; a.bias3 = s->bias3; a.es3 = s->es3;
+  a.z = y; a.ldz = ldy; a.zout = z; a.ldo = s->C; a.hsave = hsave;
+  a.ld_in = ld_in; a.dld = s->dld; a.ld_out = ld_out; a.has_ld = ld_out != nullptr;
+  a.HW = HW; a.C = s->C; a.Cout = s->Cout; a.additive = s->additive;
+  NFK_TRY(launch_coupling_inv(a, s->B, st));
   ChanMixArgs m{};
   m.x = z; m.ldx = s->C; m.Wm = s->Wi; m.cv = s->ci; m.z = xout; m.ldz = s->C; m.M = M; m.C = s->C;
   return launch_chanmix(m, st);
+}
+
+// Backward of nfk_step2d_inv (see include/nfk.h).  The inverse step is  y -> [coupling^-1 with NN(y1)] -> z -> z Wi + ci -> x;
+// the coupling net is evaluated on y1 exactly as the forward evaluates it on z1, so its backward is the forward step's:
+// the same dgrad / weight-gradient GEMMs on the activations nfk_step2d_inv kept, in their plain (one launch per GEMM) form.
+int nfk_step2d_inv_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const float* y, int ldy, const float* z,
+                       const float* h1, const float* h2, const float* hsave, const float* g_xout, const float* g_ld,
+                       float* g_y, float* ws, void* stream) {
+  hipStream_t st = S_(stream);
+  const int B = s->B, H = s->H, W = s->W, C = s->C, Ch = C / 2, hid = s->hidden, Cout = s->Cout;
+  const int M = B * H * W, HW = H * W, bf = s->bf16;
+  if (!s->Wi || !hsave || !g->mix_part) return NFK_ERR_ARG;
+  const StepBwdWs L = step_bwd_layout(s);
+  float *ga3 = ws + L.ga3, *gz = ws + L.gz, *ga2 = ws + L.ga2, *ga1 = ws + L.ga1, *d1 = ws + L.d1slab;
+  float *col2 = ws + L.col2, *col1 = ws + L.col1, *tail = ws + L.tail, *wslab = ws + L.wslab;
+  // inverse channel mix: g_z = Wi^T g_x, partial (g_Wi, g_ci) rows
+  ChanMixArgs m{};
+  m.x = g_xout; m.ldx = C; m.Wm = s->Wi; m.cv = nullptr; m.z = gz; m.ldz = C; m.M = M; m.C = C; m.trans = 1;
+  m.xin = z; m.ldxin = C; m.part = g->mix_part;
+  NFK_TRY(launch_chanmix(m, st));
+  CouplingBwdArgs cb{};
+  cb.gout = gz; cb.ldg = C; cb.gld = g_ld; cb.z = y; cb.ldz = ldy; cb.h = hsave; cb.es3 = s->es3; cb.ga3 = ga3;
+  cb.gz = g_y; cb.ldgz = C; cb.part = tail; cb.HW = HW; cb.C = C; cb.Cout = Cout; cb.additive = s->additive;
+  NFK_TRY(launch_coupling_inv_bwd(cb, B, st));
+  auto conv_bwd = [&](const ConvGemmArgs& dg, const WgradArgs& wg, int Sw, int Co, int Ci, int taps, float* gw) -> int {
+    NFK_TRY(bf ? wgrad_gemm_bf16(wg, Sw, st) : wgrad_gemm(wg, Sw, st));
+    NFK_TRY(wgrad_finalize(wg.out, Sw, wg.slab_stride, Co, Ci, taps, gw, st));
+    return run_conv(bf, dg, st);
+  };
+  WgradArgs w3{};
+  w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;
+  w3.B = B; w3.H = H; w3.W = W; w3.out = wslab; w3.slab_stride = (long)Cout * 9 * hid; w3.qbf16 = bf;
+  ConvGemmArgs d3 = conv_args(ga3, Cout, B, H, W, Cout, 9, s->wd3, hid, ga2, hid, EPI_DGRAD, bf, 1, bf);
+  d3.e1 = s->es2; d3.hprev = h2; d3.ldh = hid; d3.colsum = col2;
+  NFK_TRY(conv_bwd(d3, w3, L.S3w, Cout, hid, 9, g->g_w3));
+  WgradArgs w2{};
+  w2.P = ga2; w2.ldp = hid; w2.NI = hid; w2.Q = h1; w2.ldq = hid; w2.Cq = hid; w2.taps = 1;
+  w2.B = B; w2.H = H; w2.W = W; w2.out = wslab + L.ws3; w2.slab_stride = (long)hid * hid; w2.pbf16 = bf; w2.qbf16 = bf;
+  ConvGemmArgs d2 = conv_args(ga2, hid, B, H, W, hid, 1, s->wd2, hid, ga1, hid, EPI_DGRAD, bf, !bf, bf);
+  d2.e1 = s->es1; d2.hprev = h1; d2.ldh = hid; d2.colsum = col1;
+  NFK_TRY(conv_bwd(d2, w2, L.S2w, hid, hid, 1, g->g_w2));
+  WgradArgs w1{};
+  w1.P = ga1; w1.ldp = hid; w1.NI = hid; w1.Q = y; w1.ldq = ldy; w1.Cq = Ch; w1.taps = 9;
+  w1.B = B; w1.H = H; w1.W = W; w1.out = wslab + L.ws3 + L.ws2; w1.slab_stride = (long)hid * 9 * Ch; w1.pbf16 = bf;
+  ConvGemmArgs d1a = conv_args(ga1, hid, B, H, W, hid, 9, s->wd1, Ch, d1, Ch, EPI_RAW, bf, !bf, 0);
+  NFK_TRY(conv_bwd(d1a, w1, L.S1w, hid, Ch, 9, g->g_w1));
+  nfk_small_grad_args sg{};
+  sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = L.mb1g; sg.mb2 = L.mb2g; sg.B = B;
+  sg.n1 = hid; sg.n2 = hid; sg.n3 = Cout;
+  sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3; sg.g_l3 = g->g_l3;
+  NFK_TRY(launch_small_grads(sg, st));
+  // dL/dy1 = dL/dz1 (y1 passes through the coupling) + the coupling net's input gradient
+  return launch_add_slabs(gz, C, nullptr, 0, d1, L.S1, (long)M * Ch, g_y, C, M, Ch, st);
 }
 
 // What a step's backward still owes when its weight-gradient launch has been merged with the channel-mix launch
@@ -361,7 +420,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
     return run_conv(bf, dg, st);
   };
 
-  int mb1 = L.mb1, mb2 = L.mb2;
+  int mb1 = L.mb1g, mb2 = L.mb2g;
   // conv3 (block.4)
   WgradArgs w3{};
   w3.P = ga3; w3.ldp = Cout; w3.NI = Cout; w3.Q = h2; w3.ldq = hid; w3.Cq = hid; w3.taps = 9;

@@ -500,10 +500,13 @@ __global__ void __launch_bounds__(1024) coupling_inv_kernel(CouplingArgs a) {
     const float y2 = a.z[m * a.ldz + Ch + j];
     float out;
     if (a.additive) {
-      out = y2 - (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + j) + a.bias3[j]) * a.es3[j];
+      const float h = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + j) + a.bias3[j]) * a.es3[j];
+      if (a.hsave) a.hsave[m * a.Cout + j] = h;
+      out = y2 - h;
     } else {
       const float sh_ = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + 2 * j) + a.bias3[2 * j]) * a.es3[2 * j];
       const float sr = (slab_sum(a.a3, a.S, a.slab_stride, m * a.Cout + 2 * j + 1) + a.bias3[2 * j + 1]) * a.es3[2 * j + 1];
+      if (a.hsave) { a.hsave[m * a.Cout + 2 * j] = sh_; a.hsave[m * a.Cout + 2 * j + 1] = sr; }
       const float t = sr + 2.f;
       out = y2 * (1.f + expf(-t)) - sh_;   // y2 / sigmoid(t) - shift
       ls += log_sigmoidf(t);
@@ -550,6 +553,62 @@ __global__ void __launch_bounds__(256) coupling_bwd_kernel(CouplingBwdArgs a) {
         // d/dsr [ (z2+shift) sc ] = (z2+shift) sc (1-sc);  d/dsr log sc = 1 - sc
         const float gsr = g2 * (z2 + shf) * sc * (1.f - sc) + gl * (1.f - sc);
         a.gz[m * a.ldgz + Ch + j] = gshift;
+        const float ga0 = gshift * a.es3[2 * j], ga1 = gsr * a.es3[2 * j + 1];
+        a.ga3[m * a.Cout + 2 * j] = ga0;
+        a.ga3[m * a.Cout + 2 * j + 1] = ga1;
+        sb0 += ga0; sl0 += gshift * shf; sb1 += ga1; sl1 += gsr * sr;
+      }
+    }
+    float* row = acc + (long)g * 4 * C2;
+    row[j] = sb0; row[C2 + j] = sl0; row[2 * C2 + j] = sb1; row[3 * C2 + j] = sl1;
+  }
+  __syncthreads();
+  for (int jj = threadIdx.x; jj < C2; jj += blockDim.x) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int gg = 0; gg < G; ++gg) {
+      const float* row = acc + (long)gg * 4 * C2;
+      t0 += row[jj]; t1 += row[C2 + jj]; t2 += row[2 * C2 + jj]; t3 += row[3 * C2 + jj];
+    }
+    float* part = a.part + (long)b * 2 * a.Cout;
+    if (a.additive) { part[jj] = t0; part[a.Cout + jj] = 3.f * t1; }
+    else {
+      part[2 * jj] = t0; part[2 * jj + 1] = t2;
+      part[a.Cout + 2 * jj] = 3.f * t1; part[a.Cout + 2 * jj + 1] = 3.f * t3;
+    }
+  }
+}
+
+// backward of the INVERSE coupling tail (reverse pass with gradients, pl_module.py:229-243 on image flows):
+//   z2 = y2 / sigmoid(sr + 2) - shift   (additive: z2 = y2 - h),   logdet_out = logdet_in - dld - sum log sigmoid(sr + 2)
+// a.gout = dL/dz (the mixed tensor the inverse channel mix reads), a.z = the step's saved input y, a.h = (shift | sr) kept
+// by coupling_inv_kernel; writes dL/dy2 into a.gz's second half, the conv-net output gradient g_a3 and the same partial
+// rows as coupling_bwd_kernel.  (The first half of dL/dy is dL/dz1 + the coupling net's input gradient: added by the caller.)
+__global__ void __launch_bounds__(256) coupling_inv_bwd_kernel(CouplingBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
+  const long mb = (long)b * a.HW;
+  const float gl = a.gld ? a.gld[b] : 0.f;
+  const int G = blockDim.x / C2 > 0 ? blockDim.x / C2 : 1;
+  const int j = threadIdx.x % C2, g = threadIdx.x / C2;
+  float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
+  if (g < G && (int)threadIdx.x < G * C2) {
+    for (int p = g; p < a.HW; p += G) {
+      const long m = mb + p;
+      const float g2 = a.gout[m * a.ldg + Ch + j];
+      if (a.additive) {
+        const float h = a.h[m * a.Cout + j];
+        a.gz[m * a.ldgz + Ch + j] = g2;
+        const float ga = -g2 * a.es3[j];
+        a.ga3[m * a.Cout + j] = ga;
+        sb0 += ga; sl0 += -g2 * h;
+      } else {
+        const float shf = a.h[m * a.Cout + 2 * j], sr = a.h[m * a.Cout + 2 * j + 1];
+        const float isc = 1.f + expf(-(sr + 2.f)), sc = 1.f / isc;   // 1 / sigmoid, sigmoid
+        const float y2 = a.z[m * a.ldz + Ch + j];
+        const float gshift = -g2;
+        // d/dsr [ y2 / sc ] = -y2 (1 - sc) / sc ;  d/dsr [ -log sc ] = -(1 - sc)
+        const float gsr = -(g2 * y2 * isc + gl) * (1.f - sc);
+        a.gz[m * a.ldgz + Ch + j] = g2 * isc;
         const float ga0 = gshift * a.es3[2 * j], ga1 = gsr * a.es3[2 * j + 1];
         a.ga3[m * a.Cout + 2 * j] = ga0;
         a.ga3[m * a.Cout + 2 * j + 1] = ga1;
@@ -906,6 +965,13 @@ int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st) {
     if (C2 > 256) return NFK_ERR_ARG;
     hipLaunchKernelGGL(coupling_bwd_kernel, dim3(B), dim3(256), (size_t)(256 / C2) * 4 * C2 * sizeof(float), st, a);
   }
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+int launch_coupling_inv_bwd(const CouplingBwdArgs& a, int B, hipStream_t st) {
+  const int C2 = a.C - a.C / 2;
+  if (C2 > 256) return NFK_ERR_ARG;
+  hipLaunchKernelGGL(coupling_inv_bwd_kernel, dim3(B), dim3(256), (size_t)(256 / C2) * 4 * C2 * sizeof(float), st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

@@ -194,6 +194,7 @@ int chanmix_parts(int M, int C);
 int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st);
 int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st);
 int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
+int launch_coupling_inv_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
 int launch_squeeze_nchw(float* x, const float* noise, float* out, int B, int C, int H, int W, hipStream_t st);
 int launch_squeeze_nhwc(const float* x, int ldx, float* out, int B, int C, int H, int W, hipStream_t st);
 int launch_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st);

@@ -359,11 +359,14 @@ class FlowEngine:
         return list(res[:-1]), res[-1]
 
     def decode(self, z, y_onehot, temperature, eps=None):
-        """Reverse pass.  `eps`: {layer index: N(0,1) tensor [B,C/2,H,W]} for Split2d.  1-D flows carry gradients
-        (the perceptual branch of the tabular distillation loss, pl_module.py:229-243) when autograd is recording and a
-        parameter or `z` requires them; the 2-D reverse pass is sampling-only (its perceptual weight is 0 upstream)."""
-        if self.is_1d and torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.params())):
-            return list(_DecodeFn.apply(self, z, y_onehot, *self.params()))
+        """Reverse pass.  `eps`: {layer index: N(0,1) tensor [B,C/2,H,W]} for Split2d.  It carries gradients (the
+        perceptual branch of the distillation loss, pl_module.py:229-243) when autograd is recording and a parameter or `z`
+        requires them: wrt every FlowStep parameter and `z`.  Split2d's draw is torch.normal(mean, std) upstream
+        (models/layers.py:26-29), which is not differentiable: its prior conv gets no gradient from a reverse pass."""
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.params())):
+            if self.is_1d:
+                return list(_DecodeFn.apply(self, z, y_onehot, *self.params()))
+            return list(_Decode2dFn.apply(self, z, temperature, eps, *self.params()))
         with torch.no_grad():
             return self._decode_nograd(z, y_onehot, temperature, eps)
 
@@ -388,7 +391,7 @@ class FlowEngine:
                 M_ = B * r.H * r.W
                 out = torch.empty((B, r.H, r.W, r.C), device=z.device, dtype=torch.float32)
                 zb, h1, h2, ws = scratch.get(M_ * r.C, M_ * r.hid, M_ * r.hid, lib.nfk_step2d_fwd_ws_floats(C.byref(r.cs)))
-                check(lib.nfk_step2d_inv(C.byref(r.cs), ptr(cur), r.C, None, ptr(zb), ptr(h1), ptr(h2), ptr(ws),
+                check(lib.nfk_step2d_inv(C.byref(r.cs), ptr(cur), r.C, None, ptr(zb), ptr(h1), ptr(h2), None, ptr(ws),
                                          ptr(out), None, s), "nfk_step2d_inv")
                 cur = out
                 outs.append(out.permute(0, 3, 1, 2))
@@ -534,6 +537,143 @@ class _DecodeFn(torch.autograd.Function):
             check(lib.nfk_prep_inv_bwd(ptr(st["prep_dev"]), ptr(grad_dev), st["n_prep"], None, B, s), "nfk_prep_inv_bwd")
         gz = g if ctx.needs_input_grad[1] else None
         return (None, gz, g_y if want_gy else None) + (None,) * len(eng.params())
+
+
+class _Decode2dFn(torch.autograd.Function):
+    """The reverse pass of an image FlowNet (models/kd_flows.py:55-73) with gradients, as one autograd node: every FlowStep
+    through nfk_step2d_inv / nfk_step2d_inv_bwd; Split2d concatenates a draw that carries no gradient (torch.normal
+    upstream), so its backward is the first half of the incoming gradient; unsqueeze's backward is squeeze."""
+
+    @staticmethod
+    def forward(ctx, eng, z, temperature, eps, *params):
+        st = eng._ensure_for_decode(z)
+        eng._refresh(st, True)
+        ctx.set_materialize_grads(False)
+        lib, s = capi.lib(), capi.stream()
+        B, dev = z.shape[0], z.device
+        cur = _nhwc(z.detach().to(torch.float32))
+        scratch = _Scratch(st, dev)
+        recs = st["recs"]
+        outs, saved = [], []
+        for n, r in enumerate(reversed(recs)):
+            last = n == len(recs) - 1
+            if r.kind == "step":
+                M_ = B * r.H * r.W
+                out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                o1 = _a4(M_ * r.C)
+                o2 = o1 + _a4(M_ * r.hid)
+                o3 = o2 + _a4(M_ * r.hid)
+                arena = torch.empty(o3 + _a4(M_ * r.Cout), device=dev, dtype=torch.float32)
+                zb, h1, h2, hs = arena[:o1], arena[o1:o2], arena[o2:o3], arena[o3:]
+                (ws,) = scratch.get(lib.nfk_step2d_fwd_ws_floats(C.byref(r.cs)))
+                check(lib.nfk_step2d_inv(C.byref(r.cs), ptr(cur), r.C, None, ptr(zb), ptr(h1), ptr(h2), ptr(hs), ptr(ws),
+                                         ptr(out), None, s), "nfk_step2d_inv")
+                saved.append((cur, zb, h1, h2, hs, arena))
+                cur = out
+                outs.append(out.permute(0, 3, 1, 2))
+            elif r.kind == "split":
+                out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                e = None
+                T = 0.0 if temperature is None else float(temperature)
+                if eps is not None and r.idx in eps:
+                    e = _nhwc(eps[r.idx].to(torch.float32))
+                elif T != 0.0:
+                    e = torch.randn((B, r.H, r.W, r.C // 2), device=dev, dtype=torch.float32)
+                (ws,) = scratch.get(lib.nfk_split2d_fwd_ws_floats(C.byref(r.cs)))
+                check(lib.nfk_split2d_inv(C.byref(r.cs), ptr(cur), ptr(e), T, ptr(out), ptr(ws), s), "nfk_split2d_inv")
+                saved.append(None)
+                cur = out
+                outs.append(out.permute(0, 3, 1, 2))
+            else:  # unsqueeze: r holds the UNsqueezed dims
+                if last:
+                    out = torch.empty((B, r.C, r.H, r.W), device=dev, dtype=torch.float32)
+                    check(lib.nfk_unsqueeze(ptr(cur), ptr(out), B, r.C, r.H, r.W, 1, s), "nfk_unsqueeze")
+                    outs.append(out)
+                else:
+                    out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                    check(lib.nfk_unsqueeze(ptr(cur), ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze")
+                    outs.append(out.permute(0, 3, 1, 2))
+                saved.append(None)
+                cur = out
+        ctx.eng, ctx.st, ctx.saved, ctx.B = eng, st, saved, B
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        eng, st, B = ctx.eng, ctx.st, ctx.B
+        lib, s = capi.lib(), capi.stream()
+        recs = st["recs"]
+        dec = list(reversed(recs))           # decode order: output n came from dec[n]
+        dev = st["prep_dev"].device
+        for p in eng.params():
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+        scratch = _Scratch(st, dev)
+        part_off, total = {}, 0
+        for r in recs:
+            if r.kind == "step":
+                if r.C > 74:
+                    raise RuntimeError("reverse-pass gradients support at most 74 channels per step")
+                nb = lib.nfk_chanmix_blocks(B * r.H * r.W, r.C)
+                part_off[r.idx] = (total, nb)
+                total += _a4(nb * (r.C * r.C + r.C))
+        parts = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
+        used = set()
+        g = None   # dL/d(output of dec[n]) in that output's memory layout (NHWC; NCHW for the last layer)
+        for n in reversed(range(len(dec))):
+            r, go = dec[n], g_outs[n]
+            last = n == len(dec) - 1
+            if go is not None:
+                go = go.to(torch.float32)
+                go = go.contiguous() if (last and r.kind == "squeeze") else _nhwc(go)
+                g = go if g is None else g + go
+            if g is None:
+                continue
+            if r.kind == "step":
+                y, zb, h1, h2, hs, _ = ctx.saved[n]
+                blk = r.mod.block
+                gs = Step2dGrads()
+                gs.g_w1, gs.g_b1, gs.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
+                gs.g_w2, gs.g_b2, gs.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
+                gs.g_w3, gs.g_bias3, gs.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
+                off, nb = part_off[r.idx]
+                gs.mix_part = parts.data_ptr() + 4 * off
+                gy = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                (ws,) = scratch.get(lib.nfk_step2d_bwd_ws_floats(C.byref(r.cs)))
+                check(lib.nfk_step2d_inv_bwd(C.byref(r.cs), C.byref(gs), ptr(y), r.C, ptr(zb), ptr(h1), ptr(h2), ptr(hs),
+                                             ptr(g), None, ptr(gy), ptr(ws), s), "nfk_step2d_inv_bwd")
+                used.add(r.idx)
+                g = gy
+            elif r.kind == "split":
+                g = g[..., : r.C // 2].contiguous()   # z2 is a draw: no gradient reaches the prior conv or z1 through it
+            else:  # unsqueeze: its input was the squeezed NHWC tensor
+                gi = torch.empty((B, r.H // 2, r.W // 2, 4 * r.C), device=dev, dtype=torch.float32)
+                check(lib.nfk_squeeze(ptr(g), r.C, None, ptr(gi), B, r.C, r.H, r.W, 1 if last else 0, s), "nfk_squeeze")
+                g = gi
+        pg = []
+        for r in recs:
+            d = PrepGrad()
+            if r.kind == "step" and r.idx in used:
+                off, nb = part_off[r.idx]
+                d.part, d.nparts = parts.data_ptr() + 4 * off, nb
+                an = r.mod.actnorm
+                d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
+                if r.mod.flow_permutation_type == "invconv":
+                    ic = r.mod.invconv
+                    if ic.LU_decomposed:
+                        d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
+                    else:
+                        d.g_weight = ptr(ic.weight.grad)
+            if r.kind in ("step", "split"):
+                pg.append(d)
+        if any(d.nparts > 0 for d in pg):
+            grad_dev = _cached_grad_desc(st, "inv2d", pg, dev)
+            check(lib.nfk_prep_inv_bwd(ptr(st["prep_dev"]), ptr(grad_dev), st["n_prep"], None, B, s), "nfk_prep_inv_bwd")
+        ctx.keep = (parts,)
+        gz = None
+        if ctx.needs_input_grad[1] and g is not None:
+            gz = g.permute(0, 3, 1, 2)
+        return (None, gz, None, None) + (None,) * len(eng.params())
 
 
 class _EncodeFn(torch.autograd.Function):

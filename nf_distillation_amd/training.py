@@ -207,7 +207,9 @@ class DistillationStep:
         self.student, self.teacher = student, teacher
         self.w_nll, self.w_kd, self.w_perc = nll_weight, kd_weight, perceptual_weight
         if perceptual_weight > 0 and (teacher is None or not getattr(student, "is_1d", False)):
-            # images use VGG features upstream (models/vgg_loss.py), with weight 0 in every image config
+            # images use VGG features upstream (pl_module.py:178: VGGPerceptualLoss on pretrained weights -- outside the hot
+            # path, and weight 0 in every image config).  The reverse pass itself carries gradients for image flows too
+            # (engine._Decode2dFn): a caller can put any loss on model(z=..., reverse=True)[-1].
             raise ValueError("the perceptual (L1) branch is the tabular one: it needs 1-D flows and a teacher")
         if teacher is not None:
             for p in teacher.parameters():

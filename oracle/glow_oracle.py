@@ -288,7 +288,9 @@ def made_step(sd, cfg, pfx, x, logdet, y_onehot, reverse):
 
 def split2d(sd, pfx, x, logdet, reverse, temperature=None, eps=None):
     """Split2d (models/layers.py:293-313).  In reverse, z2 = mean + exp(logs)*T*eps
-    (what torch.normal(mean, exp(logs)*T) draws, with the N(0,1) variate made explicit)."""
+    (what torch.normal(mean, exp(logs)*T) draws, with the N(0,1) variate made explicit).  torch.normal
+    (models/layers.py:26-29) is not differentiable, so the draw is detached: a reverse pass under autograd
+    sends no gradient into the prior conv."""
     if not reverse:
         c = x.shape[1]
         z1, z2 = x[:, : c // 2], x[:, c // 2 :]
@@ -298,7 +300,7 @@ def split2d(sd, pfx, x, logdet, reverse, temperature=None, eps=None):
     mean, logs = h[:, 0::2], h[:, 1::2]
     if eps is None:
         eps = torch.zeros_like(mean)
-    z2 = mean + torch.exp(logs) * temperature * eps
+    z2 = (mean + torch.exp(logs) * temperature * eps).detach()
     return torch.cat((x, z2), 1), logdet
 
 

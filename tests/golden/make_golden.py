@@ -169,6 +169,57 @@ def reverse_grad_case(name, cfg, batch, seed):
     save(name, cfg, arrays)
 
 
+def reverse_grad_2d_case(name, cfg, batch, seed):
+    """The reverse pass WITH gradients on an IMAGE flow (pl_module.py:229-243 runs it for any student whose
+    perceptual_weight > 0): x = model(z=latent, temperature=0.7, reverse=True)[-1], loss = L1(x, target) averaged over
+    every dim but the batch, then over the batch (pl_module.py:288-291).  Split2d draws with torch.normal; the N(0,1)
+    variate of each draw is recovered from the outputs ((z2 - mean) / (exp(logs) T)) and stored, so that the draw can be
+    reproduced."""
+    model, sd = build(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 23)
+    arrays = {f"sd/{k}": v for k, v in sd.items()}
+    H, W, Cimg = cfg["image_shape"]
+    with torch.no_grad():
+        x0 = torch.rand(batch, Cimg, H, W, generator=g)
+        top_shape = model.flow(x0, logdet=torch.zeros(batch), reverse=False)[0][-1].shape
+    z = torch.randn(*top_shape, generator=g).requires_grad_(True)
+    target = torch.rand(batch, Cimg, H, W, generator=g) - 0.5
+    arrays["z"], arrays["target"] = z.detach().clone(), target
+    for i, t in perms_of(model).items():
+        arrays[f"perm/{i}"] = t
+    model.train()
+    torch.manual_seed(seed + 77)
+    outs = model(z=z, y_onehot=None, temperature=0.7, reverse=True)
+    x = outs[-1]
+    per = torch.nn.L1Loss(reduction="none")(x, target)
+    per = per.mean(dim=list(range(len(per.shape)))[1:])
+    loss = per.mean()
+    loss.backward()
+    n_layers = len(model.flow.layers)
+    with torch.no_grad():
+        for n, layer in enumerate(reversed(list(model.flow.layers))):
+            if isinstance(layer, layers.Split2d):
+                o = outs[n]
+                c = o.shape[1] // 2
+                mean, logs = layer.split2d_prior(o[:, :c])
+                arrays[f"eps/{n_layers - 1 - n}"] = (o[:, c:] - mean) / (torch.exp(logs) * 0.7)
+    for i, o in enumerate(outs):
+        arrays[f"rev/{i}"] = o
+    arrays["loss"] = loss
+    arrays["grad_z"] = z.grad
+    for k, p in model.named_parameters():
+        arrays[f"grad/{k}"] = p.grad if p.grad is not None else torch.zeros_like(p)
+    save(name, cfg, arrays)
+
+
+def reverse_grad_2d_cases():
+    reverse_grad_2d_case("glow8_revgrad", base_cfg(), 2, 131)
+    reverse_grad_2d_case("glow16_additive_nolu_revgrad",
+                         base_cfg(image_shape=[16, 16, 3], hidden_channels=24, K=2, L=3, flow_coupling="additive",
+                                  LU_decomposed=False), 3, 132)
+    reverse_grad_2d_case("glow8_shuffle_revgrad", base_cfg(flow_permutation="shuffle"), 2, 133)
+
+
 def primitive_case():
     """Per-primitive vectors."""
     g = torch.Generator().manual_seed(3)
@@ -577,6 +628,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if "--round2" in sys.argv:   # added in round 2: leaves the earlier fixtures (except primitives) untouched
         round2_cases()
+        sys.exit(0)
+    if "--only-reverse-grad-2d" in sys.argv:   # round 2, later: the image flows' reverse pass with gradients
+        reverse_grad_2d_cases()
         sys.exit(0)
     if "--only-reverse-grad" in sys.argv:   # added after the other fixtures were committed: leaves them untouched
         reverse_grad_cases()

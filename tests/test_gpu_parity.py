@@ -208,3 +208,34 @@ def test_tabular_reverse_pass_gradients(name):
             assert float(got.abs().max()) < 1e-6, k
         else:
             assert rel_err(got, ref) < 1e-3, (k, rel_err(got, ref))
+
+
+REVGRAD_2D_CASES = ["glow8_revgrad", "glow16_additive_nolu_revgrad", "glow8_shuffle_revgrad"]
+
+
+@pytest.mark.parametrize("name", REVGRAD_2D_CASES)
+def test_image_reverse_pass_gradients(name):
+    """The image flows' reverse pass WITH gradients through the HIP kernels (nfk_step2d_inv + nfk_step2d_inv_bwd +
+    nfk_prep_inv_bwd; pl_module.py:229-243 with an image student): samples, the L1 loss, and the gradients of every
+    parameter and of the latent against the reference's (Split2d's torch.normal draw reproduced from its stored N(0,1)
+    variates; it carries no gradient upstream, so the prior convs' gradients must be exactly zero)."""
+    g = Golden(name)
+    model = build(g.cfg, g.group("sd"), g)
+    z = g.t("z").cuda().requires_grad_(True)
+    eps = {int(k): v.cuda() for k, v in g.group("eps").items()}
+    outs = model(z=z, y_onehot=None, temperature=0.7, reverse=True, eps=eps)
+    for i, (o, r) in enumerate(zip(outs, g.seq("rev"))):
+        assert rel_err(o.detach().cpu(), r) < 1e-4, (i, rel_err(o.detach().cpu(), r))
+    per = torch.nn.L1Loss(reduction="none")(outs[-1], g.t("target").cuda())
+    loss = per.mean(dim=(1, 2, 3)).mean()
+    assert rel_err(loss.detach().cpu(), g.t("loss")) < 1e-5
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_err(z.grad.cpu(), g.t("grad_z")) < 1e-3, rel_err(z.grad.cpu(), g.t("grad_z"))
+    for k, p in model.named_parameters():
+        ref = g.t(f"grad/{k}")
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
+        if float(ref.abs().max()) == 0.0:
+            assert float(got.abs().max()) < 1e-6, k
+        else:
+            assert rel_err(got, ref) < 1e-3, (k, rel_err(got, ref))

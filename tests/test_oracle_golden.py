@@ -212,6 +212,36 @@ def test_reverse_pass_gradients(name):
             assert rel_err(got, ref) < 5e-4, k
 
 
+REVGRAD_2D_CASES = ["glow8_revgrad", "glow16_additive_nolu_revgrad", "glow8_shuffle_revgrad"]
+
+
+@pytest.mark.parametrize("name", REVGRAD_2D_CASES)
+def test_reverse_pass_gradients_2d(name):
+    """The image flows' reverse pass under autograd (pl_module.py:229-243 with an image student): Split2d's draw is
+    torch.normal -- no gradient into its prior conv --, reproduced here from the stored N(0,1) variates."""
+    g = Golden(name)
+    cfg, sd = g.cfg, g.group("sd")
+    trainable = [k for k in sd if not O.is_buffer(k)]
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    z = g.t("z").clone().requires_grad_(True)
+    eps = {int(k): v for k, v in g.group("eps").items()}
+    outs = O.glow_reverse(sd, cfg, z, None, temperature=0.7, eps=eps, perms=_perms(g))
+    for o, r in zip(outs, g.seq("rev")):
+        assert rel_err(o, r) < 5e-5
+    loss = (outs[-1] - g.t("target")).abs().mean(dim=(1, 2, 3)).mean()
+    assert rel_err(loss, g.t("loss")) < 1e-5
+    loss.backward()
+    assert rel_err(z.grad, g.t("grad_z")) < 5e-4
+    for k in trainable:
+        ref = g.t(f"grad/{k}")
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(ref)
+        if float(ref.abs().max()) == 0.0:
+            assert float(got.abs().max()) < 1e-7, k
+        else:
+            assert rel_err(got, ref) < 5e-4, k
+
+
 def test_tabular_distillation_step_with_perceptual_branch():
     """conf/training/tabular.yaml weights (nll 0.85, kd 0.05, perceptual-l1 0.1): two steps incl. reverse passes."""
     g = Golden("distill_tab6")
