@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
   tab_layout(s, true, &L, smem);
-  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nout = tab_nout(s), nin0 = tab_nin0(s);
+  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s);
   const int NP = tab_param_floats(s), NM = d * d + d;
   for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
   for (int i = threadIdx.x; i < NM; i += blockDim.x) L.PM[i] = 0.f;
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256) tab_inv_bwd_kernel(TabStep s, const float
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
   tab_layout(s, true, &L, smem);
-  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s);
+  const int d = s.d, Ch = d / 2, TR = L.TR, nin0 = tab_nin0(s);
   const int NP = tab_param_floats(s), NM = d * d + d;
   for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
   for (int i = threadIdx.x; i < NM; i += blockDim.x) L.PM[i] = 0.f;
