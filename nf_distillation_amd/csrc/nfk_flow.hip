@@ -25,12 +25,62 @@ namespace nfk {
 constexpr size_t PREP_INV_BWD_LDS = 152 * 1024;   // seven C x C matrices: C <= 74
 constexpr size_t PREP_LDS = 60 * 1024, PREP_BWD_LDS = 60 * 1024;   // dynamic LDS of prep_kernel / prep_bwd_kernel
 // C[n][n] = A * B   (opA/opB: 0 = as is, 1 = transposed)
+// Block-wide batch of dot products over k = 0..n-1, at most EP per thread, ALL of a thread's outputs advancing together:
+// one pass over k with 2 EP LDS reads in flight per step.  (One output after the other, every output was a chain of n
+// dependent read -> fma steps at full LDS latency: 37 us for the LU chain of a 48-channel step, measured with clock stamps.)
+// addr(idx, pa, sa, pb, sb): the two operand rows of output idx (pointer, stride in floats); out(idx, v) stores it.
+template <int EP, typename FA, typename FO>
+__device__ __forceinline__ void blk_dots(int total, int n, FA addr, FO out) {
+  const float* pa[EP];
+  const float* pb[EP];
+  int sa[EP], sb[EP];
+  float s[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int idx = threadIdx.x + e * blockDim.x;
+    addr(idx < total ? idx : 0, pa[e], sa[e], pb[e], sb[e]);
+    s[e] = 0.f;
+  }
+#pragma unroll 2
+  for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      s[e] += pa[e][0] * pb[e][0];
+      pa[e] += sa[e];
+      pb[e] += sb[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int idx = threadIdx.x + e * blockDim.x;
+    if (idx < total) out(idx, e, s[e]);
+  }
+}
+constexpr int DOT_EP = 10;   // outputs per thread of the batched form: n * n <= 10 * 256 (n <= 50: every image level up to C = 48)
+
 __device__ __forceinline__ void blk_matmul(const float* A, int ta, const float* B, int tb, float* C, int n) {
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    const int i = idx / n, j = idx % n;
-    float s = 0.f;
-    for (int k = 0; k < n; ++k) s += (ta ? A[k * n + i] : A[i * n + k]) * (tb ? B[j * n + k] : B[k * n + j]);
-    C[idx] = s;
+  const int ak = ta ? n : 1, ai = ta ? 1 : n, bk = tb ? 1 : n, bj = tb ? n : 1;
+  if (n * n <= DOT_EP * (int)blockDim.x) {
+    blk_dots<DOT_EP>(n * n, n,
+                     [&](int idx, const float*& pa, int& sa, const float*& pb, int& sb) {
+                       pa = A + (idx / n) * ai; sa = ak; pb = B + (idx % n) * bj; sb = bk;
+                     },
+                     [&](int idx, int, float v) { C[idx] = v; });
+  } else {
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+      const int i = idx / n, j = idx % n;
+      const float* a = A + i * ai;
+      const float* b = B + j * bj;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int k = 0;
+      for (; k + 4 <= n; k += 4) {
+        const float a0 = a[k * ak], a1 = a[(k + 1) * ak], a2 = a[(k + 2) * ak], a3 = a[(k + 3) * ak];
+        const float b0 = b[k * bk], b1 = b[(k + 1) * bk], b2 = b[(k + 2) * bk], b3 = b[(k + 3) * bk];
+        s0 += a0 * b0; s1 += a1 * b1; s2 += a2 * b2; s3 += a3 * b3;
+      }
+      for (; k < n; ++k) s0 += a[k * ak] * b[k * bk];
+      C[idx] = (s0 + s1) + (s2 + s3);
+    }
   }
   __syncthreads();
 }
@@ -224,20 +274,28 @@ __global__ void __launch_bounds__(256) part_reduce_kernel(const PrepDesc* __rest
 // term).  T0, T1, T2, Wk: C*C scratch matrices (T0 / T1 are overwritten with L / U).  Block-wide; accumulates.
 // pre (optional): this thread's elements idx = threadIdx.x + e * blockDim.x of `lower`, `upper` and of the diagonal
 // s = sign_s * exp(log_s), loaded by the caller at the start of the kernel (LU_PF per array; only when C*C fits)
-constexpr int LU_PF = 9;
-struct LuPre { float lo[LU_PF], up[LU_PF], sd[LU_PF]; };
-__device__ __forceinline__ void lu_preload(const PrepDesc& d, int C, LuPre& pre) {
+constexpr int LU_PF = 10;   // C * C <= 10 * 256: every image level up to C = 48 (and 1-D flows up to d = 50)
+struct LuPre { float lo[LU_PF], up[LU_PF], sd[LU_PF], old[LU_PF]; };
+// (old: the element of g_lower / g_upper / g_log_s that output idx of the chain is added to)
+__device__ __forceinline__ float* lu_target(const PrepGrad& g, int C, int idx) {
+  const int i = idx / C, j = idx % C;
+  return i > j ? g.g_lower + idx : (i < j ? g.g_upper + idx : g.g_log_s + i);
+}
+__device__ __forceinline__ void lu_preload(const PrepDesc& d, const PrepGrad& g, int C, LuPre& pre) {
 #pragma unroll
   for (int e = 0; e < LU_PF; ++e) {
     const int idx = min((int)(threadIdx.x + e * blockDim.x), C * C - 1), i = idx / C;
     pre.lo[e] = d.lower[idx];
     pre.up[e] = d.upper[idx];
     pre.sd[e] = d.sign_s[i] * expf(d.log_s[i]);
+    pre.old[e] = *lu_target(g, C, idx);
   }
 }
 __device__ __forceinline__ void prep_lu_chain(const PrepDesc& d, const PrepGrad& g, int C, const float* P, const float* GW, float* Wk,
                               float* T0, float* T1, float* T2, float Gs, const LuPre* pre = nullptr) {
   const int CC = C * C;
+  // T0 = L (unit lower), T1 = U^T (U = strict upper + diag s): transposed, so that both dot products below read their
+  // second operand along consecutive columns (U itself: a 16-way bank conflict per read at C = 48)
   if (pre) {
 #pragma unroll
     for (int e = 0; e < LU_PF; ++e) {
@@ -245,27 +303,44 @@ __device__ __forceinline__ void prep_lu_chain(const PrepDesc& d, const PrepGrad&
       if (idx < CC) {
         const int i = idx / C, j = idx % C;
         T0[idx] = i > j ? pre->lo[e] : (i == j ? 1.f : 0.f);
-        T1[idx] = i < j ? pre->up[e] : (i == j ? pre->sd[e] : 0.f);
+        T1[j * C + i] = i < j ? pre->up[e] : (i == j ? pre->sd[e] : 0.f);
       }
     }
   } else {
     for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
       const int i = idx / C, j = idx % C;
       T0[idx] = i > j ? d.lower[idx] : (i == j ? 1.f : 0.f);
-      T1[idx] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
+      T1[j * C + i] = i < j ? d.upper[idx] : (i == j ? d.sign_s[i] * expf(d.log_s[i]) : 0.f);
     }
   }
   __syncthreads();
   blk_matmul(P, 1, GW, 0, T2, C);     // T2 = P^T gW
-  blk_matmul(T2, 0, T1, 1, Wk, C);    // Wk = P^T gW U^T   -> g_L
-  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x)
-    if (idx / C > idx % C) g.g_lower[idx] += Wk[idx];
-  __syncthreads();
-  blk_matmul(T0, 1, T2, 0, Wk, C);    // Wk = L^T P^T gW    -> g_U
-  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+  // g_L = strict lower part of T2 U^T, g_U / g_s = upper part + diagonal of L^T T2: every (i, j) needs ONE of the two dot
+  // products.  The triangular factors sit in T0 / T1 as full matrices with their zeros: every output runs over all k, so
+  // that the outputs of a thread advance together (blk_dots).  The gradient elements the results are added to come in
+  // `pre`, requested at the start of the kernel (as a read-modify-write per output each was a memory round trip).
+  auto pick = [&](int idx, const float*& pa, int& sa, const float*& pb, int& sb) {
     const int i = idx / C, j = idx % C;
-    if (i < j) g.g_upper[idx] += Wk[idx];
-    else if (i == j) g.g_log_s[i] += Wk[idx] * d.sign_s[i] * expf(d.log_s[i]) + Gs;
+    if (i > j) { pa = T2 + i * C; sa = 1; pb = T1 + j; sb = C; }    // sum_k T2[i][k] U[j][k]
+    else { pa = T0 + i; sa = C; pb = T2 + j; sb = C; }               // sum_k L[k][i] T2[k][j]
+  };
+  if (pre) {
+    float res[LU_PF];
+    blk_dots<LU_PF>(CC, C, pick, [&](int, int e, float v) { res[e] = v; });
+#pragma unroll
+    for (int e = 0; e < LU_PF; ++e) {
+      const int idx = threadIdx.x + e * blockDim.x;
+      if (idx < CC) *lu_target(g, C, idx) = pre->old[e] + (idx / C == idx % C ? res[e] * pre->sd[e] + Gs : res[e]);
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
+      const float* pa; const float* pb; int sa, sb;
+      pick(idx, pa, sa, pb, sb);
+      float v = 0.f;
+      for (int k = 0; k < C; ++k) v += pa[k * sa] * pb[k * sb];
+      const int i = idx / C;
+      *lu_target(g, C, idx) += (i == idx % C) ? v * d.sign_s[i] * expf(d.log_s[i]) + Gs : v;
+    }
   }
 }
 
@@ -275,7 +350,7 @@ __device__ __forceinline__ void prep_lu_chain(const PrepDesc& d, const PrepGrad&
 // that, after inlining, the LDS instance addresses LDS with ds_ instructions (a pointer selected at run time between the
 // two would make every access a flat load: same latency as global memory).
 __device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad& g, const float* __restrict__ gld, int B,
-                                              float* base, const bool copy_p, float* sh) {
+                                              float* base, const bool copy_p, float* sh, float* vec) {
   const int C = d.C, CC = C * C;
   float* W = base;
   float* T0 = W + CC;
@@ -293,36 +368,63 @@ __device__ __forceinline__ void prep_bwd_body(const PrepDesc& d, const PrepGrad&
   // registers, Wf into the W work matrix (free until the LU chain writes it)
   LuPre pre;
   const bool use_pre = d.perm_kind == PERM_LU && CC <= LU_PF * (int)blockDim.x;
-  if (use_pre) lu_preload(d, C, pre);
-  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) W[idx] = d.Wf[idx];
+  if (use_pre) lu_preload(d, g, C, pre);
+  // Wf -> W and the reduced partials -> T0 / T1: all of a thread's loads go out before the first one is waited for
+  constexpr int EP = 10;
+  if (CC + C <= EP * (int)blockDim.x) {
+    float wv[EP], pv[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const int idx = threadIdx.x + e * blockDim.x;
+      wv[e] = idx < CC ? d.Wf[idx] : 0.f;
+      pv[e] = idx < CC + C ? g.part[idx] : 0.f;   // slab 0 holds the total (part_reduce_kernel)
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const int idx = threadIdx.x + e * blockDim.x;
+      if (idx < CC) { W[idx] = wv[e]; T0[idx] = pv[e]; }
+      else if (idx < CC + C) T1[idx - CC] = pv[e];
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) W[idx] = d.Wf[idx];
+    for (int idx = threadIdx.x; idx < CC + C; idx += blockDim.x) {
+      const float s = g.part[idx];
+      if (idx < CC) T0[idx] = s; else T1[idx - CC] = s;
+    }
+  }
+  // ActNorm's bias and e^{logs} once into LDS (they were re-read from memory per matrix element below), and the two
+  // per-channel gradients this body accumulates into, requested now and written at the end
+  float* vb = vec;
+  float* ve = vec + C;
+  float old_b = 0.f, old_l = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { vb[c] = d.an_bias[c]; ve[c] = expf(d.an_logs[c]); }
+  if ((int)threadIdx.x < C) { old_b = g.g_an_bias[threadIdx.x]; old_l = g.g_an_logs[threadIdx.x]; }
 
   float G = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) G += gld[b];
   G = block_sum(G, sh) * (float)d.pixels;
-
-  // reduce partials (fixed order): GWf -> T0 ; gcf -> T1[0..C)
-  for (int idx = threadIdx.x; idx < CC + C; idx += blockDim.x) {
-    const float s = g.part[idx];  // slab 0 holds the total (part_reduce_kernel)
-    if (idx < CC) T0[idx] = s; else T1[idx - CC] = s;
-  }
   __syncthreads();
   // g_bias[c] = sum_o Wf[o][c] gcf[o];  gWf_tot = gWf + gcf b^T
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float t = 0.f;
-    for (int o = 0; o < C; ++o) t += W[o * C + c] * T1[o];
-    g.g_an_bias[c] += t;
+    float t0 = 0.f, t1 = 0.f;
+    int o = 0;
+    for (; o + 2 <= C; o += 2) { t0 += W[o * C + c] * T1[o]; t1 += W[(o + 1) * C + c] * T1[o + 1]; }
+    if (o < C) t0 += W[o * C + c] * T1[o];
+    if (c == (int)threadIdx.x) g.g_an_bias[c] = old_b + (t0 + t1); else g.g_an_bias[c] += t0 + t1;
   }
-  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) T0[idx] += T1[idx / C] * d.an_bias[idx % C];
+  for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) T0[idx] += T1[idx / C] * vb[idx % C];
   __syncthreads();
   // g_logs[c] = sum_o gWf_tot[o][c] Wf[o][c] + G ;  gW (in W's own index convention) -> GW
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float t = 0.f;
-    for (int o = 0; o < C; ++o) t += T0[o * C + c] * W[o * C + c];
-    g.g_an_logs[c] += t + G;
+    float t0 = 0.f, t1 = 0.f;
+    int o = 0;
+    for (; o + 2 <= C; o += 2) { t0 += T0[o * C + c] * W[o * C + c]; t1 += T0[(o + 1) * C + c] * W[(o + 1) * C + c]; }
+    if (o < C) t0 += T0[o * C + c] * W[o * C + c];
+    if (c == (int)threadIdx.x) g.g_an_logs[c] = old_l + (t0 + t1) + G; else g.g_an_logs[c] += (t0 + t1) + G;
   }
   for (int idx = threadIdx.x; idx < CC; idx += blockDim.x) {
     const int o = idx / C, c = idx % C;
-    const float v = T0[idx] * expf(d.an_logs[c]);
+    const float v = T0[idx] * ve[c];
     if (d.is_1d) GW[c * C + o] = v; else GW[idx] = v;
   }
   __syncthreads();
@@ -333,14 +435,15 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
                                                        const PrepGrad* __restrict__ grads,
                                                        const float* __restrict__ gld, int B) {
   __shared__ float sh[32];
+  __shared__ float vec[2 * 256];   // ActNorm bias | e^{logs} of the step (C <= 256)
   const PrepDesc d = descs[blockIdx.x];
   const PrepGrad g = grads[blockIdx.x];
-  if (d.C == 0) return;
+  if (d.C == 0 || d.C > 256) return;
   // the C x C work matrices (and P) live in LDS when six of them fit the 60 KiB the launch provides (C <= 50);
   // wider steps fall back to the step's global scratch
   extern __shared__ __attribute__((aligned(16))) float pb_lds[];
-  if ((size_t)6 * d.C * d.C * sizeof(float) <= PREP_BWD_LDS) prep_bwd_body(d, g, gld, B, pb_lds, true, sh);
-  else prep_bwd_body(d, g, gld, B, d.scratch, false, sh);
+  if ((size_t)6 * d.C * d.C * sizeof(float) <= PREP_BWD_LDS) prep_bwd_body(d, g, gld, B, pb_lds, true, sh, vec);
+  else prep_bwd_body(d, g, gld, B, d.scratch, false, sh, vec);
 }
 
 // Dense-weight variant needs GW after the inverse; done in a second tiny kernel to keep scratch small.

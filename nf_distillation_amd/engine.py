@@ -204,6 +204,8 @@ class FlowEngine:
             if r.kind in ("step", "tab"):
                 an = layer.actnorm
                 _check_param(an.bias, "actnorm.bias")
+                if r.C > 256:
+                    raise ValueError("a FlowStep mixes at most 256 channels / features (prep kernels' LDS vectors)")
                 d.C, d.pixels, d.is_1d = r.C, r.H * r.W, 1 if layer.is_1d else 0
                 d.an_bias, d.an_logs = ptr(an.bias), ptr(an.logs)
                 if layer.flow_permutation_type == "invconv":
