@@ -201,6 +201,9 @@ int nfk_coupling_inv(const float *a3, int S, const float *bias3, const float *es
 int nfk_squeeze(float *x, int ldx, const float *noise, float *out, int B, int C, int H, int W, int from_nchw,
                 void *stream);
 int nfk_unsqueeze(const float *y, float *out, int B, int C, int H, int W, int to_nchw, void *stream);
+/* unsqueeze2d of y + y2 (same layout): the backward of a squeeze whose output is also a distillation hint receives two
+ * gradients (kd_flows.py:42-53 returns that output; pl_module.py:262-282 puts an MSE on it) -- summed on the way through */
+int nfk_unsqueeze_add(const float *y, const float *y2, float *out, int B, int C, int H, int W, int to_nchw, void *stream);
 /* Glow.normal_flow tail (models/kd_flows.py:136-150): objective = logdet + log N(z; prior), bits/dim */
 int nfk_prior_fwd(const float *z, int ldz, const float *prior, long prior_bstride, const float *ld,
                   float *objective, float *bpd, int B, int HW, int C, float bpd_scale, void *stream);

@@ -144,6 +144,7 @@ _PROTOS = {
     "nfk_coupling_inv": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nfk_squeeze": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nfk_unsqueeze": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nfk_unsqueeze_add": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nfk_prior_fwd": (i32, [vp, i32, vp, lng, vp, vp, vp, i32, i32, i32, f32, vp]),
     "nfk_prior_bwd": (i32, [vp, i32, vp, lng, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nfk_step2d_fwd": (i32, [C.POINTER(Step2d), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -228,7 +228,10 @@ int nfk_squeeze(float* x, int ldx, const float* noise, float* out, int B, int C,
   return launch_squeeze_nhwc(x, ldx, out, B, C, H, W, S_(stream));
 }
 int nfk_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, void* stream) {
-  return launch_unsqueeze(y, out, B, C, H, W, to_nchw, S_(stream));
+  return launch_unsqueeze(y, nullptr, out, B, C, H, W, to_nchw, S_(stream));
+}
+int nfk_unsqueeze_add(const float* y, const float* y2, float* out, int B, int C, int H, int W, int to_nchw, void* stream) {
+  return launch_unsqueeze(y, y2, out, B, C, H, W, to_nchw, S_(stream));
 }
 
 int nfk_prior_fwd(const float* z, int ldz, const float* prior, long prior_bstride, const float* ld,

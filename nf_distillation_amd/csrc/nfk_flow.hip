@@ -769,27 +769,29 @@ __global__ void squeeze_nhwc_kernel(const float* __restrict__ x, int ldx, float*
   }
 }
 // NHWC squeezed -> NHWC unsqueezed (also the backward of squeeze_nhwc)
-__global__ void unsqueeze_nhwc_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int C, int H,
-                                      int W) {  // (C,H,W) = UNsqueezed dims
+__global__ void unsqueeze_nhwc_kernel(const float* __restrict__ y, const float* __restrict__ y2, float* __restrict__ out, int B,
+                                      int C, int H, int W) {  // (C,H,W) = UNsqueezed dims; y2: optional second addend
   const int Ho = H / 2, Wo = W / 2, Co = 4 * C;
   const long total = (long)B * H * W * C;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int c = t % C; long r = t / C;
     const int w = r % W; r /= W;
     const int h = r % H; const int b = r / H;
-    out[t] = y[(((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * Co + c * 4 + (h & 1) * 2 + (w & 1)];
+    const long src = (((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * Co + c * 4 + (h & 1) * 2 + (w & 1);
+    out[t] = y2 ? y[src] + y2[src] : y[src];
   }
 }
 // NHWC squeezed -> NCHW unsqueezed (model boundary of the reverse pass / grad wrt input image)
-__global__ void unsqueeze_to_nchw_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int C, int H,
-                                         int W) {
+__global__ void unsqueeze_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ y2, float* __restrict__ out,
+                                         int B, int C, int H, int W) {
   const int Ho = H / 2, Wo = W / 2, Co = 4 * C;
   const long total = (long)B * C * H * W;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int w = t % W; long r = t / W;
     const int h = r % H; r /= H;
     const int c = r % C; const int b = r / C;
-    out[t] = y[(((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * Co + c * 4 + (h & 1) * 2 + (w & 1)];
+    const long src = (((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * Co + c * 4 + (h & 1) * 2 + (w & 1);
+    out[t] = y2 ? y[src] + y2[src] : y[src];
   }
 }
 
@@ -1092,13 +1094,13 @@ int launch_squeeze_nhwc(const float* x, int ldx, float* out, int B, int C, int H
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
-int launch_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st) {
+int launch_unsqueeze(const float* y, const float* y2, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st) {
   if ((H | W) & 1) return NFK_ERR_ARG;
   if (to_nchw)
-    hipLaunchKernelGGL(unsqueeze_to_nchw_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, y, out,
+    hipLaunchKernelGGL(unsqueeze_to_nchw_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, y, y2, out,
                        B, C, H, W);
   else
-    hipLaunchKernelGGL(unsqueeze_nhwc_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, y, out, B,
+    hipLaunchKernelGGL(unsqueeze_nhwc_kernel, dim3(ew_blocks((long)B * C * H * W)), dim3(256), 0, st, y, y2, out, B,
                        C, H, W);
   NFK_LAUNCH_CHECK();
   return NFK_OK;

@@ -197,7 +197,7 @@ int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
 int launch_coupling_inv_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
 int launch_squeeze_nchw(float* x, const float* noise, float* out, int B, int C, int H, int W, hipStream_t st);
 int launch_squeeze_nhwc(const float* x, int ldx, float* out, int B, int C, int H, int W, hipStream_t st);
-int launch_unsqueeze(const float* y, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st);
+int launch_unsqueeze(const float* y, const float* y2, float* out, int B, int C, int H, int W, int to_nchw, hipStream_t st);
 int launch_split_fwd(const SplitArgs& a, int B, hipStream_t st);
 int launch_split_inv(const SplitArgs& a, int B, hipStream_t st);
 int launch_split_bwd(const SplitBwdArgs& a, int B, hipStream_t st);

@@ -1060,18 +1060,19 @@ class _EncodeFn(torch.autograd.Function):
                 if eng.grad_hook is not None:
                     eng.grad_hook(r.idx)
             else:  # squeeze: grad of the input = unsqueeze of the grad
-                tot = g if ext is None else (ext if g is None else g + ext)
                 first = r is recs[0]
                 if first and not ctx.needs_input_grad[1]:
                     g = None
                     continue
+                # (a squeeze output that is also a hint arrives as two gradients: summed inside the unsqueeze launch)
+                g_a, g_b = (g, ext) if g is not None else (ext, None)
                 if first and ctx.x_contig:
                     gx = torch.empty((B, r.C, r.H, r.W), device=dev, dtype=torch.float32)
-                    check(lib.nfk_unsqueeze(ptr(tot), ptr(gx), B, r.C, r.H, r.W, 1, s), "nfk_unsqueeze")
+                    check(lib.nfk_unsqueeze_add(ptr(g_a), ptr(g_b), ptr(gx), B, r.C, r.H, r.W, 1, s), "nfk_unsqueeze_add")
                     g = gx
                 else:
                     gx = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
-                    check(lib.nfk_unsqueeze(ptr(tot), ptr(gx), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze")
+                    check(lib.nfk_unsqueeze_add(ptr(g_a), ptr(g_b), ptr(gx), B, r.C, r.H, r.W, 0, s), "nfk_unsqueeze_add")
                     g = gx if not first else gx.permute(0, 3, 1, 2)
 
         if pend is not None:

@@ -167,11 +167,14 @@ class _KdLossFn(torch.autograd.Function):
         ctx.keep = (s_list, t_list, nll, weights)
         ctx.n_pairs = n_pairs
         ctx.mark_non_differentiable(kd)
+        ctx.set_materialize_grads(False)   # (no zero tensors for the three outputs nothing differentiates: 3 fill launches)
         return out3[0], out3[1].detach(), out3[2].detach(), kd
 
     @staticmethod
     def backward(ctx, g_result, _g1, _g2, _g3):
         s_list, _, nll, weights = ctx.keep
+        if g_result is None:
+            return (None,) * (6 + 2 * len(s_list))
         g = g_result.detach().to(torch.float32).reshape(1).contiguous()
         grads = capi.KdGrads()
         g_s = [torch.empty_like(s) for s in s_list]   # preserves the (channels-last) strides
