@@ -331,6 +331,18 @@ typedef struct nfk_fused_run {
 int nfk_run2d_fused_ok(const nfk_step2d *s);
 int nfk_run2d_fwd_fused(const nfk_fused_run *run, const nfk_step2d *first, void *stream);
 int nfk_ld_finish(const float *ld_in, const float *ldpart, int nsteps, int B, int tiles, float *ld_out, void *stream);
+/* The same for up to NFK_LD_MAX_PARTS partial buffers in sequence (the steps of a level, the Split2d behind it, the next
+ * level, ...): the arithmetic of one nfk_ld_finish per buffer, each continuing from the previous result, in ONE launch
+ * (nothing between them reads the running log-det).  `parts` is a host array. */
+#define NFK_LD_MAX_PARTS 8
+typedef struct nfk_ld_parts {
+  const float *part;       /* [nsteps][B][tiles] */
+  int32_t nsteps, tiles;
+} nfk_ld_parts;
+int nfk_ld_finish_multi(const float *ld_in, const nfk_ld_parts *parts, int n, int B, float *ld_out, void *stream);
+/* Workgroups per sample whose log-density partials nfk_split2d_fwd leaves at the start of `ws` when it is called with
+ * ld_out == NULL on a geometry nfk_split2d_fused_ok accepts (0 otherwise): to be finished by nfk_ld_finish(_multi). */
+int nfk_split2d_fwd_tiles(const nfk_split2d *s);
 /* Split2d.forward / reverse / backward */
 int nfk_split2d_fwd(const nfk_split2d *s, const float *x, const float *ld_in, float *z1out, float *hsave,
                     float *ws, float *ld_out, void *stream);

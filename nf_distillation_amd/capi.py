@@ -73,6 +73,13 @@ class Step2dNext(C.Structure):
     _fields_ = [("s", C.POINTER(Step2d)), ("z", c_fp), ("hsave", c_fp), ("g_ext", c_fp), ("ws", c_fp), ("ga", c_fp)]
 
 
+LD_MAX_PARTS = 8
+
+
+class LdParts(C.Structure):
+    _fields_ = [("part", c_fp), ("nsteps", C.c_int32), ("tiles", C.c_int32)]
+
+
 class Split2d(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("bias", c_fp), ("es", c_fp), ("wt", c_fp), ("wd", c_fp), ("w", c_fp)]
@@ -130,6 +137,8 @@ _PROTOS = {
     "nfk_split2d_fwd_ws_floats": (u64, [C.POINTER(Split2d)]),
     "nfk_split2d_bwd_ws_floats": (u64, [C.POINTER(Split2d)]),
     "nfk_split2d_fused_ok": (i32, [C.POINTER(Split2d)]),
+    "nfk_split2d_fwd_tiles": (i32, [C.POINTER(Split2d)]),
+    "nfk_ld_finish_multi": (i32, [vp, C.POINTER(LdParts), i32, i32, vp, vp]),
     "nfk_prep": (i32, [vp, i32, i32, vp]),
     "nfk_prep_bwd": (i32, [vp, vp, i32, vp, i32, i32, vp]),
     "nfk_prep_inv_bwd": (i32, [vp, vp, i32, vp, i32, vp]),

@@ -157,6 +157,7 @@ size_t nfk_split2d_bwd_ws_floats(const nfk_split2d* s) {
   const size_t fused = align4(nt * 2 * s->C) + align4(nt * s->C * 9 * Ch);
   return gemm > fused ? gemm : fused;
 }
+int nfk_split2d_fwd_tiles(const nfk_split2d* s) { return nfk_split2d_fused_ok(s) ? split2d_fused_tps(*s) : 0; }
 int nfk_split2d_fused_ok(const nfk_split2d* s) { return (s->w && g_split_fused && split2d_fused_tiles(*s) > 0) ? 1 : 0; }
 
 int nfk_prep(const nfk_prep_desc* descs, int nsteps, int want_inverse, void* stream) {

@@ -934,6 +934,26 @@ __global__ void ld_finish_kernel(const float* __restrict__ ld_in, const float* _
   ld_out[b] = v;
 }
 
+// Several partial buffers in sequence (the FlowSteps of a level, a Split2d, the next level, ...): exactly the arithmetic of
+// one ld_finish_kernel launch per buffer, each starting from the previous one's result -- bit-identical, one launch.
+struct LdMulti {
+  const float* part[NFK_LD_MAX_PARTS];
+  int nsteps[NFK_LD_MAX_PARTS], tiles[NFK_LD_MAX_PARTS];
+  int n;
+};
+__global__ void ld_finish_multi_kernel(const float* __restrict__ ld_in, LdMulti m, int B, float* __restrict__ ld_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float v = ld_in[b];
+  for (int k = 0; k < m.n; ++k) {
+    const float* __restrict__ p = m.part[k];
+    const int tps = m.tiles[k];
+    for (int st = 0; st < m.nsteps[k]; ++st)
+      for (int t = 0; t < tps; ++t) v += p[((long)st * B + b) * tps + t];
+  }
+  ld_out[b] = v;
+}
+
 static unsigned long long* g_stamps = nullptr;   // diagnostic only (nfk_fused_set_stamps)
 
 }  // namespace nfk
@@ -995,6 +1015,17 @@ int nfk_run2d_fwd_fused(const nfk_fused_run* run, const nfk_step2d* first, void*
   return rc;
 }
 
+int nfk_ld_finish_multi(const float* ld_in, const nfk_ld_parts* parts, int n, int B, float* ld_out, void* stream) {
+  if (B <= 0) return NFK_OK;
+  if (n < 0 || n > NFK_LD_MAX_PARTS || (n > 0 && !parts)) return NFK_ERR_ARG;
+  LdMulti m{};
+  m.n = n;
+  for (int k = 0; k < n; ++k) { m.part[k] = parts[k].part; m.nsteps[k] = parts[k].nsteps; m.tiles[k] = parts[k].tiles; }
+  hipLaunchKernelGGL(ld_finish_multi_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ld_in, m,
+                     B, ld_out);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
 int nfk_ld_finish(const float* ld_in, const float* ldpart, int nsteps, int B, int tps, float* ld_out, void* stream) {
   if (B <= 0) return NFK_OK;
   hipLaunchKernelGGL(ld_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ld_in,

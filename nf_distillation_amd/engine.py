@@ -710,6 +710,25 @@ class _EncodeFn(torch.autograd.Function):
         cur, cur_ld = None, None  # NHWC tensor of the running activation
         run, keep_alive = None, []
         skip_until = 0
+        # log-det partials of the fused launches (a level's steps, the fused Split2d) are summed onto `ld` in ONE launch where
+        # the running value is next needed -- normally at the end of the pass: same arithmetic in the same order as one
+        # finishing launch per buffer (nfk_ld_finish_multi)
+        pending = []
+
+        def flush_ld(cur_ld):
+            out_ld = cur_ld
+            while pending:
+                chunk = pending[:capi.LD_MAX_PARTS]
+                del pending[:capi.LD_MAX_PARTS]
+                arr = (capi.LdParts * len(chunk))()
+                for k_, (buf_, ns_, tl_) in enumerate(chunk):
+                    arr[k_].part, arr[k_].nsteps, arr[k_].tiles = buf_.data_ptr(), ns_, tl_
+                    keep_alive.append(buf_)
+                nxt = torch.empty_like(out_ld)
+                check(lib.nfk_ld_finish_multi(ptr(out_ld), arr, len(chunk), B, ptr(nxt), s), "nfk_ld_finish_multi")
+                out_ld = nxt
+            return out_ld
+
         use_runs = eng.fused and eng.bf16 and (eng.fused_runs is True or (eng.fused_runs == "inference" and not need))
         for r in st["recs"]:
             if r.idx < skip_until:
@@ -745,10 +764,7 @@ class _EncodeFn(torch.autograd.Function):
                 fr.zout, fr.zout_stride = zo_all.data_ptr(), zc
                 fr.keep = sum(1 << k for k in kept)
                 check(lib.nfk_run2d_fwd_fused(C.byref(fr), C.byref(r.cs), s), "nfk_run2d_fwd_fused")
-                ld_out = torch.empty_like(ld)
-                check(lib.nfk_ld_finish(ptr(ld), ptr(ldbuf), n, B, tiles, ptr(ld_out), s), "nfk_ld_finish")
-                ld = ld_out
-                keep_alive.append(ldbuf)
+                pending.append((ldbuf, n, tiles))
                 slot = 0
                 for k in range(n):
                     out = None
@@ -833,16 +849,14 @@ class _EncodeFn(torch.autograd.Function):
                                                part, ptr(ws), ptr(masks), ways, s), "nfk_step2d_fwd_fused")
                 run["k"] += 1
                 if run["k"] == run["n"]:
-                    ld_out = torch.empty_like(ld)
-                    check(lib.nfk_ld_finish(ptr(ld), ptr(run["buf"]), run["n"], B, tiles, ptr(ld_out), s), "nfk_ld_finish")
-                    ld = ld_out
-                    keep_alive.append(run["buf"])
+                    pending.append((run["buf"], run["n"], tiles))
                     run = None
             elif r.kind == "step":
                 if cur is None:
                     cur = _nhwc(x)
                 M_ = B * r.H * r.W
                 out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                ld = flush_ld(ld)   # this launch reads the running log-det
                 ld_out = torch.empty_like(ld)
                 nws = lib.nfk_step2d_fwd_ws_floats(C.byref(r.cs))
                 if need:
@@ -866,19 +880,28 @@ class _EncodeFn(torch.autograd.Function):
                     cur = _nhwc(x)
                 M_ = B * r.H * r.W
                 out = torch.empty((B, r.H, r.W, r.C // 2), device=dev, dtype=torch.float32)
-                ld_out = torch.empty_like(ld)
                 hs = torch.empty(M_ * r.C, device=dev, dtype=torch.float32) if need else None
-                (ws,) = scratch.get(lib.nfk_split2d_fwd_ws_floats(C.byref(r.cs)))
-                check(lib.nfk_split2d_fwd(C.byref(r.cs), ptr(cur), ptr(ld), ptr(out), ptr(hs), ptr(ws), ptr(ld_out), s),
-                      "nfk_split2d_fwd")
+                sp_tiles = lib.nfk_split2d_fwd_tiles(C.byref(r.cs))
+                if sp_tiles > 0:   # one fused launch that leaves per-tile partials: finished with the others
+                    lbuf = torch.empty(max(B * sp_tiles, 4), device=dev, dtype=torch.float32)
+                    check(lib.nfk_split2d_fwd(C.byref(r.cs), ptr(cur), None, ptr(out), ptr(hs), ptr(lbuf), None, s),
+                          "nfk_split2d_fwd")
+                    pending.append((lbuf, 1, sp_tiles))
+                else:
+                    ld = flush_ld(ld)
+                    ld_out = torch.empty_like(ld)
+                    (ws,) = scratch.get(lib.nfk_split2d_fwd_ws_floats(C.byref(r.cs)))
+                    check(lib.nfk_split2d_fwd(C.byref(r.cs), ptr(cur), ptr(ld), ptr(out), ptr(hs), ptr(ws), ptr(ld_out), s),
+                          "nfk_split2d_fwd")
+                    ld = ld_out
                 saved.append((cur, hs) if need else None)
-                ld = ld_out
             cur = out
             outs.append(out.permute(0, 3, 1, 2) if (keep is None or r.idx in keep) else None)
             if r is st["recs"][0] and eng.first_layer_hook is not None:
                 eng.first_layer_hook()  # the model input has been consumed (and dequantised in place)
             if r.idx in eng.layer_hooks:
                 eng.layer_hooks[r.idx]()
+        ld = flush_ld(ld)
         ctx.saved = saved
         ctx.x_contig = x.is_contiguous()
         return tuple(outs) + (ld,)
