@@ -122,8 +122,9 @@ class Leg:
         if self.pipelined:
             # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
             # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py)
-            from nf_distillation_amd.pipeline import PipelinedStep
-            self.runner = PipelinedStep(self.step, data[0], strict=self.world == 1)
+            from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep
+            cls = AheadPipelinedStep if getattr(a, "teacher_ahead", 1) == 2 else PipelinedStep
+            self.runner = cls(self.step, data[0], strict=self.world == 1)
             if getattr(a, "teacher_start_layer", None) is not None:   # experiment knob (-1: fork at the start of the call)
                 self.runner.teacher_starts_after_layer = None if a.teacher_start_layer < 0 else a.teacher_start_layer
             self.runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
@@ -140,7 +141,9 @@ class Leg:
     def schedule(self):
         """What is actually running, read from the runner (never from the flags)."""
         graph = getattr(self.runner, "graph", None) is not None
-        if graph and self.pipelined:
+        if graph and self.pipelined and getattr(self.args, "teacher_ahead", 1) == 2:
+            s = "hipGraph replay (three graphs), teacher two batches ahead: teacher(t+2) launched under all-reduce / optimiser (t)"
+        elif graph and self.pipelined:
             s = "hipGraph replay, teacher(t+1) || student(t) software pipeline"
         elif graph:
             s = "hipGraph replay"
@@ -275,6 +278,9 @@ def main():
                     help="experiment knobs: pairs for nfk_tune(knob, value) (include/nfk.h NFK_TUNE_*)")
     ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_step2d_grads.bwd_mode of the student "
                                                                  "(1 separate launches, 3 one launch per conv, 4 / default fused)")
+    ap.add_argument("--teacher-ahead", type=int, default=1, choices=(1, 2),
+                    help="2: the teacher runs two batches ahead, its forward launched under the gradient all-reduce "
+                         "(pipeline.AheadPipelinedStep; opt-in until an RCCL run has been possible)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "

@@ -225,3 +225,155 @@ class PipelinedStep:
         self.step.allreduce()
         self.step.optimize()
         return out
+
+
+class AheadPipelinedStep(PipelinedStep):
+    """The software pipeline with the teacher TWO batches ahead, so that the gradient all-reduce is overlapped in graph mode.
+
+    Several ranks replay `student fwd+bwd -> (eager all-reduce) -> clip + Adam`; during the all-reduce the GPU has nothing to
+    compute, and cutting the student's backward into bucket-sized graphs is not possible from inside `loss.backward()` (the
+    engine's backward runs on autograd's device thread; a capture must end on the thread that began it).  The frozen teacher
+    offers the work instead: its forward for batch t+2 is LAUNCHED right after the student's backward of batch t, as a graph
+    of its own on the side stream, so it runs under the all-reduce and the optimiser of batch t (and then beside the student
+    of batch t+1, as before).  What the student's chain no longer has to share the chip with is as long as the collective.
+    Every call still does one teacher forward, one student forward + backward, one all-reduce and one optimiser step, on the
+    same values in the same order (bit-identical parameters: tests/test_gpu_pipeline.py, tests/test_gpu_ddp.py).
+
+    Call pattern: `prime(x0, x1)`, then `training_step(x_{t+2})` trains on batch t and returns its losses, `drain()` (twice
+    the work of the base class: two batches are in flight) returns the losses of the last two batches.  Opt-in
+    (`bench.py --teacher-ahead 2`): no RCCL run has been possible on this repo's one-GPU boxes, and the plain
+    `PipelinedStep` keeps the N-rank path as simple as it can be until one has.
+    """
+
+    def __init__(self, step, example_x, use_graph=True, warmup=2, with_noise=False, strict=False):
+        super().__init__(step, example_x, use_graph, warmup, with_noise, strict)
+        self.main = torch.cuda.Stream()
+        self.ev_t, self.ev_h = torch.cuda.Event(), torch.cuda.Event()
+        self.graph_t = None
+        if step.world > 1:
+            step.set_allreduce_overlap(False)   # one all-reduce after the backward, under the teacher's next forward
+
+    # ---- building blocks (each runs on the stream named in its comment)
+    def _teacher_async(self, x, noise_s, noise_t):
+        """side stream: wait for the handover, load batch `x`, run (or replay) the teacher branch"""
+        self.side.wait_event(self.ev_h)
+        with torch.cuda.stream(self.side):
+            self._load(x, noise_s, noise_t)
+            if self.graph_t is not None:
+                self.graph_t.replay()
+            else:
+                self._teacher_branch()
+            self.ev_t.record(self.side)
+
+    def _handover_main(self):
+        """main stream: the teacher's outputs of the batch the student trains on next become current"""
+        self.main.wait_event(self.ev_t)
+        self._handover()
+        self.ev_h.record(self.main)
+
+    def _student(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.out
+        return self._student_fwd_bwd()
+
+    def _finish(self):
+        if self.graph is not None:
+            self.step.reducer.reset()   # (a replayed backward does not run the Python that resets the bucket state)
+        self.step.allreduce()
+        if self.graph_b is not None:
+            self.graph_b.replay()
+        else:
+            self.step.optimize()
+
+    def _clone_out(self, out):
+        return {k: v.clone() for k, v in out.items()}
+
+    # ---- public API
+    def prime(self, x0, x1=None, noise_s=None, noise_t=None, noise_s1=None, noise_t1=None):
+        """teacher(x0) -> handover -> teacher(x1) in flight.  x1 defaults to x0 (benchmarks that cycle one batch)."""
+        x1 = x0 if x1 is None else x1
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.main):
+            self.ev_h.record(self.main)
+        self._teacher_async(x0, noise_s, noise_t)
+        with torch.cuda.stream(self.main):
+            self._handover_main()
+        self._teacher_async(x1, noise_s1 if noise_s1 is not None else noise_s, noise_t1 if noise_t1 is not None else noise_t)
+        cur.wait_stream(self.main)
+        self.primed = True
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        gt, ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gt, stream=self.side):
+            self._teacher_branch()
+        with torch.cuda.graph(ga, stream=self.main):
+            self.out = self._student_fwd_bwd()
+        with torch.cuda.graph(gb, stream=self.main):
+            self.step.optimize()
+        self.graph_t, self.graph, self.graph_b = gt, ga, gb
+
+    def _iteration(self, x_new, noise_s, noise_t):
+        """student(t) || teacher(t+1) [in flight] -> handover -> teacher(t+2) launched -> all-reduce(t) -> optimiser(t)"""
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        self.side.wait_stream(cur)   # (x_new was produced on the caller's stream)
+        with torch.cuda.stream(self.main):
+            out = self._student()
+            if x_new is not None:
+                self._handover_main()
+        if x_new is not None:
+            self._teacher_async(x_new, noise_s, noise_t)
+        with torch.cuda.stream(self.main):
+            self._finish()
+        cur.wait_stream(self.main)
+        return out
+
+    def training_step(self, x_next, noise_s=None, noise_t=None):
+        if not self.primed:
+            raise RuntimeError("call prime(first_batch, second_batch) first")
+        if self.use_graph and self.graph is None:
+            if self._warm > 0:
+                self._warm -= 1
+            else:
+                # the capture itself consumes nothing: it records the launches of one teacher branch / one student pass /
+                # one optimiser step without running them (the buffers they touch are the static ones)
+                torch.cuda.synchronize()
+                try:
+                    self._capture_guarded()
+                except Exception as exc:  # pragma: no cover - depends on the runtime
+                    if self.strict:
+                        raise
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the pipelined step failed ({exc!r}); running eagerly")
+                    self.use_graph = False
+                    self.graph = self.graph_b = self.graph_t = None
+                    torch.cuda.synchronize()
+        return self._iteration(x_next, noise_s, noise_t)
+
+    def _capture_guarded(self):
+        """Capture must not disturb the values in flight: the teacher's outputs for the next batch sit in t_next / x_stu_next
+        and the batch after it in x_in.  Nothing executes during capture, but the RNG offsets of the captured uniform draws
+        are registered with the graph-safe generator, and zero_grad / the reducer are reset by the replays themselves."""
+        self._capture()
+
+    def prepare(self, x0, noise_s=None, noise_t=None):
+        self.prime(x0, x0, noise_s, noise_t)
+        while self.use_graph and self.graph is None:
+            self.training_step(x0, noise_s, noise_t)
+
+    def drain(self):
+        """Train on the two batches still in flight (no new teacher work); returns the losses of both, oldest first."""
+        first = self._clone_out(self._iteration(None, None, None))
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.main):
+            self._handover_main()
+            second = self._student()
+            self._finish()
+        cur.wait_stream(self.main)
+        self.primed = False
+        return [first, second]

@@ -51,6 +51,14 @@ def _worker(rank, world, port, out_dir):
         for _ in range(3):
             runner.training_step(xs, nss, nts)
         runner.drain()
+    elif os.environ.get("NFK_TEST_GRAPH") == "3":   # teacher two batches ahead: its forward runs under the all-reduce
+        from nf_distillation_amd.pipeline import AheadPipelinedStep
+        runner = AheadPipelinedStep(step, xs, warmup=1, with_noise=True)
+        runner.prime(xs, xs, nss, nts)
+        for _ in range(2):
+            runner.training_step(xs, nss, nts)
+        runner.drain()
+        assert runner.graph_t is not None, "the teacher branch was not captured"
     else:
         for _ in range(4):
             runner.training_step(xs.clone(), nss, nts)
@@ -62,11 +70,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", ["eager", "graph", "pipelined_graph"])
+@pytest.mark.parametrize("graph", ["eager", "graph", "pipelined_graph", "teacher_ahead_graph"])
 def test_two_ranks_equal_one_rank(tmp_path, graph):
     from golden_util import Golden
     from nf_distillation_amd.training import DistillationStep
-    mode = {"eager": 0, "graph": 1, "pipelined_graph": 2}[graph]
+    mode = {"eager": 0, "graph": 1, "pipelined_graph": 2, "teacher_ahead_graph": 3}[graph]
     port = 29700 + os.getpid() % 1000 + 7 * mode
     os.environ["NFK_TEST_GRAPH"] = str(mode)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
