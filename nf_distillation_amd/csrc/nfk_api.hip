@@ -395,6 +395,8 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   cb.gout = g_out; cb.ldg = C; cb.gext = g_ext; cb.ldge = C; cb.gld = g_ld; cb.z = z; cb.ldz = C; cb.h = hsave;
   cb.es3 = s->es3; cb.ga3 = ga3; cb.gz = gz; cb.ldgz = C; cb.part = tail; cb.HW = HW; cb.C = C; cb.Cout = Cout;
   cb.additive = s->additive;
+  const int cpl_tiles = coupling_bwd_tiles(B, HW);   // stand-alone coupling backward: B * cpl_tiles workgroups / partial rows
+  cb.tiles = cpl_tiles;
   if (coupling_rows <= 0) NFK_TRY(launch_coupling_bwd(cb, B, st));   // else: done by the previous call of the chain
   // Each conv's weight gradient (slabs -> finalize) and dgrad read the same output gradient and are independent.
   // bf16 "dual" mode runs the two GEMMs as ONE launch on the caller's stream; otherwise the weight gradient goes to
@@ -508,7 +510,7 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
 
   nfk_small_grad_args sg{};
   sg.col1 = col1; sg.col2 = col2; sg.tail = tail; sg.mb1 = mb1; sg.mb2 = mb2;
-  sg.B = coupling_rows > 0 ? coupling_rows : B;
+  sg.B = coupling_rows > 0 ? coupling_rows : B * cpl_tiles;
   sg.n1 = fused_deferred ? 0 : hid; sg.n2 = fused_deferred ? 0 : hid; sg.n3 = Cout;
   sg.g_l1 = g->g_l1; sg.g_b1 = g->g_b1; sg.g_l2 = g->g_l2; sg.g_b2 = g->g_b2; sg.g_bias3 = g->g_bias3;
   sg.g_l3 = g->g_l3;

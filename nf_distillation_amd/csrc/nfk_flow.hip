@@ -630,15 +630,17 @@ __global__ void __launch_bounds__(1024) coupling_inv_kernel(CouplingArgs a) {
 
 __global__ void __launch_bounds__(256) coupling_bwd_kernel(CouplingBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float acc[];  // [G][4][C2] per-group column sums
-  const int b = blockIdx.x, Ch = a.C / 2, C2 = a.C - Ch;
-  const long mb = (long)b * a.HW;
+  // a.tiles workgroups per sample (pixel ranges of HW / tiles): one partial row each
+  const int T = a.tiles > 0 ? a.tiles : 1, b = blockIdx.x / T, tile = blockIdx.x - b * T, PT = a.HW / T;
+  const int Ch = a.C / 2, C2 = a.C - Ch;
+  const long mb = (long)b * a.HW + (long)tile * PT;
   const float gl = a.gld ? a.gld[b] : 0.f;
   // thread (g, j): column j, pixels g, g+G, ...; column sums reduced over g in fixed order via LDS
   const int G = blockDim.x / C2 > 0 ? blockDim.x / C2 : 1;
   const int j = threadIdx.x % C2, g = threadIdx.x / C2;
   float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
   if (g < G && (int)threadIdx.x < G * C2) {
-    for (int p = g; p < a.HW; p += G) {
+    for (int p = g; p < PT; p += G) {
       const long m = mb + p;
       float g2 = a.gout[m * a.ldg + Ch + j];
       if (a.gext) g2 += a.gext[m * a.ldge + Ch + j];
@@ -672,7 +674,7 @@ __global__ void __launch_bounds__(256) coupling_bwd_kernel(CouplingBwdArgs a) {
       const float* row = acc + (long)gg * 4 * C2;
       t0 += row[jj]; t1 += row[C2 + jj]; t2 += row[2 * C2 + jj]; t3 += row[3 * C2 + jj];
     }
-    float* part = a.part + (long)b * 2 * a.Cout;
+    float* part = a.part + (long)blockIdx.x * 2 * a.Cout;
     if (a.additive) { part[jj] = t0; part[a.Cout + jj] = 3.f * t1; }
     else {
       part[2 * jj] = t0; part[2 * jj + 1] = t2;
@@ -1064,11 +1066,19 @@ int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st) {
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
-int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st) {
+// partial rows a stand-alone coupling backward writes: B * tiles (<= 256: the step's `tail` workspace)
+int coupling_bwd_tiles(int B, int HW) {
+  int T = 1;
+  while (T < 4 && B * T * 2 <= 256 && HW % (T * 2) == 0 && HW / (T * 2) >= 16) T *= 2;
+  return T;
+}
+int launch_coupling_bwd(const CouplingBwdArgs& a_in, int B, hipStream_t st) {
   {
+    CouplingBwdArgs a = a_in;
     const int C2 = a.C - a.C / 2;
     if (C2 > 256) return NFK_ERR_ARG;
-    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(B), dim3(256), (size_t)(256 / C2) * 4 * C2 * sizeof(float), st, a);
+    if (a.tiles <= 0) a.tiles = 1;
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(B * a.tiles), dim3(256), (size_t)(256 / C2) * 4 * C2 * sizeof(float), st, a);
   }
   NFK_LAUNCH_CHECK();
   return NFK_OK;

@@ -64,8 +64,9 @@ struct CouplingBwdArgs {
   const float* es3;
   float* ga3;                      // [M][Cout] = g_h * es3  (operand of dgrad3 / wgrad3)
   float* gz; int ldgz;             // [M][C]: second half written here (g_z2)
-  float* part;                     // [B][2][Cout]: (sum g_a3, 3 * sum g_h h)
+  float* part;                     // [B * tiles][2][Cout]: (sum g_a3, 3 * sum g_h h)
   int HW, C, Cout, additive;
+  int tiles;                       // stand-alone kernel: workgroups per sample (0 / 1: one); unused by the fused forms
 };
 
 struct SplitArgs {
@@ -194,6 +195,7 @@ int chanmix_parts(int M, int C);
 int launch_coupling_fwd(const CouplingArgs& a, int B, hipStream_t st);
 int launch_coupling_inv(const CouplingArgs& a, int B, hipStream_t st);
 int launch_coupling_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
+int coupling_bwd_tiles(int B, int HW);
 int launch_coupling_inv_bwd(const CouplingBwdArgs& a, int B, hipStream_t st);
 int launch_squeeze_nchw(float* x, const float* noise, float* out, int B, int C, int H, int W, hipStream_t st);
 int launch_squeeze_nhwc(const float* x, int ldx, float* out, int B, int C, int H, int W, hipStream_t st);

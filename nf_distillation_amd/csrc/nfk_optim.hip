@@ -78,9 +78,31 @@ __global__ void __launch_bounds__(256) kd_pair_sums_kernel(nfk_kd_pairs a, float
   const float* s = a.s[p] + (long)b * n;
   const float* t = a.t[p] + (long)b * n;
   float acc = 0.f;
-  for (long i = threadIdx.x; i < n; i += 256) {
-    const float d = s[i] - t[i];
-    acc += d * d;
+  if ((n & 3) == 0 && ((reinterpret_cast<size_t>(s) | reinterpret_cast<size_t>(t)) & 15) == 0) {
+    // 16-byte loads, four per operand in flight (a 3072-element hint is three passes of the block: one round trip)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(s);
+    const f4* t4 = reinterpret_cast<const f4*>(t);
+    const long n4 = n >> 2;
+    for (long i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+      f4 sv[4], tv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        sv[u] = i < n4 ? s4[i] : f4{0.f, 0.f, 0.f, 0.f};
+        tv[u] = i < n4 ? t4[i] : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f4 d = sv[u] - tv[u];
+        acc += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) {
+      const float d = s[i] - t[i];
+      acc += d * d;
+    }
   }
   acc = block_sum(acc, sh);
   if (threadIdx.x == 0) part[p * a.B + b] = acc / (float)n;
@@ -116,6 +138,28 @@ __global__ void __launch_bounds__(256) kd_bwd_kernel(nfk_kd_pairs a, const float
   const float* s = a.s[p] + (long)b * n;
   const float* t = a.t[p] + (long)b * n;
   float* o = g.g_s[p] + (long)b * n;
+  if ((n & 3) == 0 && ((reinterpret_cast<size_t>(s) | reinterpret_cast<size_t>(t) | reinterpret_cast<size_t>(o)) & 15) == 0) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(s);
+    const f4* t4 = reinterpret_cast<const f4*>(t);
+    f4* o4 = reinterpret_cast<f4*>(o);
+    const long n4 = n >> 2;
+    for (long i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+      f4 sv[4], tv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        sv[u] = i < n4 ? s4[i] : f4{0.f, 0.f, 0.f, 0.f};
+        tv[u] = i < n4 ? t4[i] : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        if (i < n4) o4[i] = (sv[u] - tv[u]) * coef;
+      }
+    }
+    return;
+  }
   for (long i = threadIdx.x; i < n; i += 256) o[i] = coef * (s[i] - t[i]);
 }
 
