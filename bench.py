@@ -23,6 +23,16 @@ Extra objects on the line (rank 0, N=1 only):
                     bf16 mode against fp32 mode; the run FAILS (exit 3) if they differ by 0.01 or more.
   cpu_baseline    : the CPU oracle (oracle/glow_oracle.py, a checked restatement of the reference)
                     running the same step on the host cores for a bounded number of steps.
+  oracle_check    : THIS geometry against the oracle (tests/oracle_check.py): the cpu_baseline leg's warm-up step (B=64,
+                    parameters of seeds 11 / 12, batch seed 100) is also run through the HIP path on the same batch and
+                    noise -- default schedule (pipelined hipGraph) in both precisions, eager step in the headline one --
+                    and step-0 nll / kd / loss / gradient norm / 64 sampled entries of every parameter gradient are
+                    compared; the run FAILS (exit 5) on a miss.
+  reference_precision_value / _ms_per_step : the f32 leg's numbers again, at top level (the reference computes in fp32;
+                    `value` is BASELINE.json's bf16 mode).
+Several ranks (N > 1): `ranks_seen` (dist.get_world_size()) and `allreduce_ms` (events around the bucketed gradient
+all-reduce, averaged over the timed steps, max over ranks); `--backend gloo` is a stand-in transport for rehearsals on
+one GPU (tests/test_gpu_bench_ranks.py).
 The run also fails (exit 4) if the step could not be captured into a hipGraph: `config.schedule` is derived from the
 runner's state, never from the flags.
 """
@@ -64,9 +74,11 @@ def make_models(device, dtype):
     return models  # student, teacher
 
 
-def cpu_baseline(batch, steps):
-    """The oracle's distill_step on the host: 1 warm-up + `steps` timed steps."""
+def cpu_baseline(batch, steps, want_digest=False):
+    """The oracle's distill_step on the host: 1 warm-up + `steps` timed steps.  The warm-up step (initial parameters,
+    batch seed 100) doubles as the oracle side of `oracle_check`: -> (cpu_baseline block, digest of that step or None)."""
     from oracle import glow_oracle as O
+    import oracle_check as OC
     from param_util import randomize_state_dict, synthetic_images
     from test_oracle_golden import full_shapes
     # a 1-GPU box gets a 16-CPU share of the host; more threads than that only thrash
@@ -80,15 +92,40 @@ def cpu_baseline(batch, steps):
     t_sd = randomize_state_dict(full_shapes(t_cfg), 12)
     state = {}
     times = []
+    digest = None
     for i in range(steps + 1):
         x, noise = synthetic_images(batch, seed=100 + i)
         t0 = time.perf_counter()
-        O.distill_step(s_sd, s_cfg, t_sd, t_cfg, x, noise, noise.clone(), state)
+        out = O.distill_step(s_sd, s_cfg, t_sd, t_cfg, x, noise, noise.clone(), state, keep_grads=want_digest and i == 0)
         times.append(time.perf_counter() - t0)
+        if want_digest and i == 0:
+            digest = OC.digest_oracle_step(out, [k for k in s_sd if not O.is_buffer(k)])
     dt = sum(times[1:]) / steps
     return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} timed steps (after 1 warm-up) of the same distillation step, B={batch}, fp32, "
-                      f"torch CPU {torch.__version__}"}
+                      f"torch CPU {torch.__version__}"}, digest
+
+
+def oracle_check(digest, batch, headline_dtype, both):
+    """HIP step vs the oracle's step on the same batch / noise / parameters (tests/oracle_check.py)."""
+    import oracle_check as OC
+    cases = [(headline_dtype, "pipelined_graph"), (headline_dtype, "eager")]
+    if both:
+        cases.append(("f32" if headline_dtype == "bf16" else "bf16", "pipelined_graph"))
+    block = {"sample": f"step 0 of the cpu_baseline leg: B={batch}, parameters of seeds {OC.SEED_STUDENT} / {OC.SEED_TEACHER}, "
+                       "batch seed 100, same dequantisation noise", "bars": OC.BARS,
+             "oracle": {k: digest[k] for k in ("nll", "kd", "result_loss", "grad_norm")}, "cases": {}}
+    ok = True
+    for dt, sched in cases:
+        scal, grads, _ = OC.hip_step(dt, sched, batch)
+        res = OC.compare(digest, scal, grads, dt)
+        res.update({k: scal[k] for k in ("nll", "kd", "result_loss", "grad_norm")})
+        block["cases"][f"{dt}/{sched}"] = res
+        ok = ok and res["ok"]
+        del grads
+        torch.cuda.empty_cache()
+    block["ok"] = ok
+    return block
 
 
 class Leg:
@@ -106,7 +143,7 @@ class Leg:
         self.step = DistillationStep(self.student, self.teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
         if not args.no_overlap:
             self.step.enable_concurrency()  # teacher fwd || student fwd, wgrad || dgrad on side streams
-        self.runner, self.pipelined = self.step, False
+        self.runner, self.pipelined, self.kind, self.fallbacks = self.step, False, "eager", []
 
     def initial_bpd(self, x, noise):
         """Student bits/dim of one batch with the initial parameters (no training)."""
@@ -114,26 +151,54 @@ class Leg:
             _, bpd, _ = self.student(x.clone(), None, noise=noise)
         return float(bpd.mean())
 
-    def capture(self):
+    def _build_runner(self, kind):
         a, data = self.args, self.data
+        if kind in ("ahead", "pipelined"):
+            # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
+            # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py).
+            # "ahead": the teacher two batches ahead, its forward launched under the gradient all-reduce
+            from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep
+            cls = AheadPipelinedStep if kind == "ahead" else PipelinedStep
+            runner = cls(self.step, data[0], strict=True)
+            if getattr(a, "teacher_start_layer", None) is not None:   # experiment knob (-1: fork at the start of the call)
+                runner.teacher_starts_after_layer = None if a.teacher_start_layer < 0 else a.teacher_start_layer
+            runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
+        elif kind == "graph":
+            from nf_distillation_amd.training import CapturedStep
+            runner = CapturedStep(self.step, data[0], strict=True)
+            runner.prepare()  # eager warm-up + capture, before the W warm-up steps
+        else:
+            self.step.set_allreduce_overlap(True)   # eager: buckets are all-reduced from inside the backward
+            runner = self.step
+        return runner
+
+    def capture(self):
+        a = self.args
         if not a.no_overlap:
             self.step.enable_concurrency()   # (the auxiliary stream is a library-wide setting: the other leg may have reset it)
-        self.pipelined = not a.no_graph and not a.no_pipeline
-        if self.pipelined:
-            # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
-            # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py)
-            from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep
-            cls = AheadPipelinedStep if getattr(a, "teacher_ahead", 1) == 2 else PipelinedStep
-            self.runner = cls(self.step, data[0], strict=self.world == 1)
-            if getattr(a, "teacher_start_layer", None) is not None:   # experiment knob (-1: fork at the start of the call)
-                self.runner.teacher_starts_after_layer = None if a.teacher_start_layer < 0 else a.teacher_start_layer
-            self.runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
-        elif not a.no_graph:
-            from nf_distillation_amd.training import CapturedStep
-            self.runner = CapturedStep(self.step, data[0], strict=self.world == 1)
-            self.runner.prepare()  # eager warm-up + capture, before the W warm-up steps
-        # one rank: a step that was not captured is a failed run.  Several ranks (RCCL beside hipGraph capture has never run
-        # in this repo's tests): fall back to eager launches and SAY so in config.schedule rather than produce no number
+        ahead = a.teacher_ahead == 2 or (a.teacher_ahead is None and self.world > 1)
+        if a.no_graph:
+            order = ["eager"]
+        elif a.no_pipeline:
+            order = ["graph", "eager"]
+        else:
+            order = (["ahead"] if ahead else []) + ["pipelined", "graph", "eager"]
+        # one rank: a step that was not captured as asked is a failed run.  Several ranks (RCCL beside hipGraph capture has
+        # never run in this repo's tests): degrade to the next simpler schedule and SAY so in config.schedule rather than
+        # produce no number
+        self.fallbacks = []
+        for kind in order:
+            try:
+                self.runner = self._build_runner(kind)
+                self.kind = kind
+                break
+            except Exception as exc:   # pragma: no cover - depends on the runtime
+                if self.world == 1:
+                    print(f"bench.py: the step was not captured into a hipGraph ({kind}: {exc!r})", file=sys.stderr)
+                    raise SystemExit(4)
+                self.fallbacks.append(f"{kind}: {exc!r}"[:200])
+                torch.cuda.synchronize()
+        self.pipelined = self.kind in ("ahead", "pipelined")
         if self.world == 1 and not a.no_graph and getattr(self.runner, "graph", None) is None:
             print("bench.py: the step was not captured into a hipGraph", file=sys.stderr)
             raise SystemExit(4)
@@ -141,7 +206,7 @@ class Leg:
     def schedule(self):
         """What is actually running, read from the runner (never from the flags)."""
         graph = getattr(self.runner, "graph", None) is not None
-        if graph and self.pipelined and getattr(self.args, "teacher_ahead", 1) == 2:
+        if graph and self.kind == "ahead":
             s = "hipGraph replay (three graphs), teacher two batches ahead: teacher(t+2) launched under all-reduce / optimiser (t)"
         elif graph and self.pipelined:
             s = "hipGraph replay, teacher(t+1) || student(t) software pipeline"
@@ -151,6 +216,8 @@ class Leg:
             s = "eager"
         if self.world > 1 and graph:
             s += ", gradient all-reduce between sub-graphs (never captured)"
+        if self.fallbacks:
+            s += " [fell back from: " + "; ".join(self.fallbacks) + "]"
         return s
 
     def run(self, n, eager=False):
@@ -259,6 +326,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling instead: fixed global batch (SURVEY.md §8d suggests 512), split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="skip the HIP-vs-oracle comparison of this geometry")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="transport of the gradient all-reduce for N > 1: nccl (= RCCL over xGMI, the product) or gloo "
+                         "(a stand-in for rehearsing the N-rank path with several ranks on one GPU)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-precision", action="store_true",
                     help="skip the second leg (the f32 parity mode beside a bf16 headline, or the reverse)")
@@ -278,9 +349,10 @@ def main():
                     help="experiment knobs: pairs for nfk_tune(knob, value) (include/nfk.h NFK_TUNE_*)")
     ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_step2d_grads.bwd_mode of the student "
                                                                  "(1 separate launches, 3 one launch per conv, 4 / default fused)")
-    ap.add_argument("--teacher-ahead", type=int, default=1, choices=(1, 2),
+    ap.add_argument("--teacher-ahead", type=int, default=None, choices=(1, 2),
                     help="2: the teacher runs two batches ahead, its forward launched under the gradient all-reduce "
-                         "(pipeline.AheadPipelinedStep; opt-in until an RCCL run has been possible)")
+                         "(pipeline.AheadPipelinedStep).  Default: 2 for N > 1 (something overlaps the collective), 1 for "
+                         "one GPU (no collective to hide; same speed)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "
@@ -299,10 +371,16 @@ def main():
         args.batch = args.global_batch // world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank
+    if args.backend == "gloo":   # rehearsal: the ranks may share a GPU
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from nf_distillation_amd import capi
     from param_util import synthetic_images
@@ -329,6 +407,8 @@ def main():
                      "ok": diff < 0.01, "sample": f"one batch of {args.batch} images, same dequantisation noise, initial parameters"}
 
     leg.capture()
+    if world > 1:
+        leg.step.reducer.enable_timing()   # (after capture / warm-up of the runner: only timed + warm-up steps are averaged)
     elapsed, last = leg.timed(args.steps, args.warmup, device)
     images = args.batch * world * args.steps
     value = images / elapsed
@@ -344,6 +424,14 @@ def main():
         "student_bpd": float(last["nll"]), "loss": float(last["result_loss"]),
         "step_roofline": step_roofline(value / world, args.dtype),
     }
+    if world > 1:
+        from nf_distillation_amd.dist import max_over_ranks
+        result["ranks_seen"] = dist.get_world_size()
+        result["backend"] = args.backend + (" (RCCL)" if args.backend == "nccl" else " (stand-in transport, not RCCL)")
+        ar = leg.step.reducer.timed_ms()
+        result["allreduce_ms"] = max_over_ranks(ar if ar is not None else 0.0, device)
+        result["allreduce_note"] = ("events on the compute stream around GradAllReducer.finish(): what is left of the bucketed "
+                                    "all-reduce after the backward has been enqueued + the wait for every bucket; max over ranks")
     if solo and leg.pipelined and not args.no_roofline:
         result["sequential_schedule"] = leg.sequential_schedule(args.steps, args.warmup)
     if solo and not args.no_roofline:
@@ -358,8 +446,22 @@ def main():
             block["roofline"] = other.roofline(args.steps)
         result["f32_parity_mode" if other.dtype == "f32" else "bf16_throughput_mode"] = block
         result["bpd_check"] = bpd_check
+    f32_block = result if args.dtype == "f32" else result.get("f32_parity_mode")
+    if f32_block is not None:
+        result["reference_precision_value"] = f32_block["value"]
+        result["reference_precision_ms_per_step"] = f32_block["ms_per_step"]
+    result["precision_note"] = (
+        "the reference computes in fp32: `reference_precision_value` (images/s, exact-f32 MFMA, meets the 1e-5 parity bar) is "
+        "the number to hold against it; `value` is BASELINE.json's bf16 mode (bf16 operands, fp32 accumulation; student "
+        "bits/dim within 0.01)" if args.dtype == "bf16" else "fp32 throughout (the reference's precision)")
+    check_block = None
     if solo and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_steps)
+        want = not args.no_oracle_check
+        del leg, other
+        torch.cuda.empty_cache()
+        result["cpu_baseline"], digest = cpu_baseline(args.batch, args.cpu_steps, want_digest=want)
+        if want:
+            check_block = result["oracle_check"] = oracle_check(digest, args.batch, args.dtype, not args.no_other_precision)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -368,6 +470,9 @@ def main():
     if bpd_check is not None and not bpd_check["ok"]:
         print("bench.py: bf16 student bits/dim differs from fp32 by >= 0.01", file=sys.stderr)
         raise SystemExit(3)
+    if check_block is not None and not check_block["ok"]:
+        print("bench.py: the HIP step at the benchmark's geometry disagrees with the oracle (oracle_check)", file=sys.stderr)
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

@@ -358,6 +358,12 @@ int nfk_step2d_inv_bwd(const nfk_step2d* s, const nfk_step2d_grads* g, const flo
 struct PendingTail {
   nfk_small_grad_args sg;   // col1 / col2 segments only (n3 = 0)
   StepTailArgs f;
+  // where the owed slabs / partial rows sit: the workspace of the step that left them and its layout's geometry.  A later
+  // call may only carry them along in its merged launch if nothing in that launch writes the same workspace under ANOTHER
+  // layout (the chained coupling backward of `next` writes next->ws + {ga3, gz, tail} of the NEW geometry: at a level
+  // boundary those offsets fall inside the old level's slab regions)
+  const float* ws;
+  int B, H, W, C, hidden, Cout;
 };
 static_assert(sizeof(PendingTail) <= sizeof(((nfk_step2d_pending*)nullptr)->blob), "nfk_step2d_pending.blob too small");
 static PendingTail* pending_of(nfk_step2d_pending* p) { return reinterpret_cast<PendingTail*>(p->blob); }
@@ -517,7 +523,13 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
   // (fused + deferred: the caller's stream still runs the one launch of coupling-tail gradients + channel mix + the next
   //  step's coupling backward, only without slab work)
   const bool have_tail = fused_deferred || (tail_f.S[0] | tail_f.S[1] | tail_f.S[2]) != 0;
-  if (pend && pend->valid && !merged) NFK_TRY(pending_flush(pend, st));   // this call cannot take the previous step's tail along
+  if (pend && pend->valid) {
+    // this call cannot take the previous step's tail along (no merged launch), or must not: the owed step belongs to
+    // another level, so its slabs sit under another layout in a workspace this launch's chained writes may touch
+    const PendingTail* pt = pending_of(pend);
+    const bool same_geom = pt->B == B && pt->H == H && pt->W == W && pt->C == C && pt->hidden == hid && pt->Cout == Cout;
+    if (!merged || !same_geom) NFK_TRY(pending_flush(pend, st));
+  }
 
   // actnorm + permutation backward: g_x = Wf^T g_z, partial (gWf, gcf) for nfk_prep_bwd
   ChanMixArgs m{};
@@ -553,25 +565,38 @@ static int step2d_bwd_impl(const nfk_step2d* s, const nfk_step2d_grads* g, const
       sx.g_l1 = pt->sg.g_l1; sx.g_b1 = pt->sg.g_b1; sx.g_l2 = pt->sg.g_l2; sx.g_b2 = pt->sg.g_b2;
       fx = pt->f;
     }
+    const bool want_chain = chained;
     int rc = wgrad_tail_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an_m, sx, fx, m, chained ? &nb : nullptr, st,
                              (double)hid * (9.0 * Cout + hid + 9.0 * Ch));
     if (rc == NFK_ERR_ARG && chained) {   // the coupling backward does not fit beside the channel mix: unchained
       chained = false;
       rc = wgrad_tail_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an_m, sx, fx, m, nullptr, st, (double)hid * (9.0 * Cout + hid + 9.0 * Ch));
     }
-    if (rc != NFK_OK) return rc;
-    if (chained && next_rows) *next_rows = chanmix_parts(M, C);
-    PendingTail* pt = pending_of(pend);
-    pt->sg = sg; pt->sg.n3 = 0; pt->sg.tail = nullptr;
-    pt->f = tail_f;
-    pend->valid = 1;
-  } else if (have_tail) {
+    if (rc == NFK_ERR_ARG) {
+      // the merged launch does not exist for this geometry (channel mix too wide for its LDS, operand rows not a multiple
+      // of 8): the three GEMMs as their own launch, what the previous step owes now, then the unmerged tail below
+      NFK_TRY(triple_wgrad_bf16(w3, L.S3f, w2, L.S2w, w1, L.S1f, an_m, st, (double)hid * (9.0 * Cout + hid + 9.0 * Ch)));
+      NFK_TRY(pending_flush(pend, st));
+      merged = false;
+      chained = want_chain;
+    } else if (rc != NFK_OK) {
+      return rc;
+    } else {
+      if (chained && next_rows) *next_rows = chanmix_parts(M, C);
+      PendingTail* pt = pending_of(pend);
+      pt->sg = sg; pt->sg.n3 = 0; pt->sg.tail = nullptr;
+      pt->f = tail_f;
+      pt->ws = ws; pt->B = B; pt->H = H; pt->W = W; pt->C = C; pt->hidden = hid; pt->Cout = Cout;
+      pend->valid = 1;
+    }
+  }
+  if (!merged && have_tail) {
     int rc = launch_tail_chanmix(sg, tail_f, m, chained ? &nb : nullptr, st);
     if (rc == NFK_OK && chained && next_rows) *next_rows = chanmix_parts(M, C);
     if (rc == NFK_ERR_ARG && chained) rc = launch_tail_chanmix(sg, tail_f, m, nullptr, st);   // does not fit: unchained
     if (rc == NFK_ERR_ARG) { NFK_TRY(launch_step_tail(sg, tail_f, st)); NFK_TRY(launch_chanmix(m, st)); }
     else if (rc != NFK_OK) return rc;
-  } else {
+  } else if (!merged) {
     NFK_TRY(launch_small_grads(sg, st));
     NFK_TRY(launch_chanmix(m, st));
   }

@@ -57,7 +57,20 @@ class GradAllReducer:
             lo = max(0, hi - per)
             self.bounds.append((lo, hi))
             hi = lo
+        self.timing = None   # list of (start, end) event pairs around finish() when timing is on (bench.py: allreduce_ms)
         self.reset()
+
+    def enable_timing(self, on=True):
+        """Bracket every finish() (what is left of the bucketed all-reduce once the backward has been enqueued, plus the
+        wait for all buckets) with events on the current stream; `timed_ms()` averages them."""
+        self.timing = [] if on else None
+
+    def timed_ms(self):
+        if not self.timing:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.timing]
+        return sum(ms) / len(ms)
 
     def reset(self):
         self.next = 0
@@ -74,9 +87,16 @@ class GradAllReducer:
     def finish(self):
         if self.world == 1:
             return
+        ev = None
+        if self.timing is not None and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self.ready(0)
         for w in self.works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
         self.reset()
 
 

@@ -249,6 +249,7 @@ class AheadPipelinedStep(PipelinedStep):
         super().__init__(step, example_x, use_graph, warmup, with_noise, strict)
         self.main = torch.cuda.Stream()
         self.ev_t, self.ev_h = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_load = torch.cuda.Event()   # the caller's batch has been copied into the static buffers (side stream)
         self.graph_t = None
         if step.world > 1:
             step.set_allreduce_overlap(False)   # one all-reduce after the backward, under the teacher's next forward
@@ -259,6 +260,7 @@ class AheadPipelinedStep(PipelinedStep):
         self.side.wait_event(self.ev_h)
         with torch.cuda.stream(self.side):
             self._load(x, noise_s, noise_t)
+            self.ev_load.record(self.side)
             if self.graph_t is not None:
                 self.graph_t.replay()
             else:
@@ -302,6 +304,7 @@ class AheadPipelinedStep(PipelinedStep):
         with torch.cuda.stream(self.main):
             self._handover_main()
         self._teacher_async(x1, noise_s1 if noise_s1 is not None else noise_s, noise_t1 if noise_t1 is not None else noise_t)
+        cur.wait_event(self.ev_load)
         cur.wait_stream(self.main)
         self.primed = True
 
@@ -327,6 +330,9 @@ class AheadPipelinedStep(PipelinedStep):
                 self._handover_main()
         if x_new is not None:
             self._teacher_async(x_new, noise_s, noise_t)
+            # the caller may free or overwrite x_new / the noise tensors once this call returns: its stream must not run
+            # ahead of the side stream's copy of them (queued behind the handover event)
+            cur.wait_event(self.ev_load)
         with torch.cuda.stream(self.main):
             self._finish()
         cur.wait_stream(self.main)

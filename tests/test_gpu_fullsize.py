@@ -135,23 +135,7 @@ def _distill_batches(g):
     return out
 
 
-class _OptState:
-    """Snapshot / restore of everything a training step changes (parameters, Adam moments, step counter), in place:
-    lets a captured graph be warmed up and captured on the real buffers and then replayed from the initial state."""
-
-    def __init__(self, step):
-        self.step = step
-        o = step.opt
-        self.bufs = [step.flat.data, o.m, o.v, o.step_dev]
-        self.saved = [b.clone() for b in self.bufs]
-        self.t = o.t
-
-    def restore(self):
-        for b, s in zip(self.bufs, self.saved):
-            b.copy_(s)
-        self.step.opt.t = self.t
-        self.step.student.flow.engine().mark_dirty()
-        torch.cuda.synchronize()
+from oracle_check import OptState as _OptState  # noqa: E402  (snapshot / restore of parameters + Adam state)
 
 
 def _unclipped(g, p):
