@@ -45,7 +45,12 @@ def test_bench_geometry_merged_weight_gradient_tail_equals_unmerged_bf16():
         (bpd.mean() + 0.05 * sum(o.square().mean() for o in outs[::7])).backward()
         torch.cuda.synchronize()
         res[(merge, chain)] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    # merged vs unmerged launches of the chained backward: the same kernels' bodies on the same data -> bit for bit
+    for k, v in res[(True, True)].items():
+        w = res[(False, True)][k]
+        assert torch.equal(v, w), ("merged", k, float((v - w).abs().max()), float(w.abs().max()))
+    # chained vs per-step calls: the coupling tail's partial rows are one per channel-mix workgroup instead of one per
+    # sample tile (another order of the same fp32 sums): 1e-6 of the tensor's largest entry
     base = res[(False, False)]
-    for key in ((True, True), (False, True)):
-        for k, v in res[key].items():
-            assert torch.equal(v, base[k]), (key, k, float((v - base[k]).abs().max()), float(base[k].abs().max()))
+    for k, v in res[(True, True)].items():
+        assert float((v - base[k]).abs().max()) <= 1e-6 * float(base[k].abs().max()) + 1e-12, ("chained", k)
