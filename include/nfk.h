@@ -281,6 +281,43 @@ int nfk_aux_join(nfk_aux *aux, void *stream);
  * and relu_masks), else 0 */
 int nfk_step2d_fused_bwd_ok(const nfk_step2d *s);
 size_t nfk_step2d_mask_bytes(const nfk_step2d *s);   /* size of nfk_step2d_fwd_fused's masksave */
+/* ---- backward of a whole LEVEL (a run of FlowSteps of one geometry; bf16 fused path) ---------------------------------
+ * Autograd of models/flows.py:142-171 through all K steps of a level, as the mirror of nfk_run2d_fwd_fused:
+ *   per step ONE launch  [dgrad chain -> channel-mix backward (g_x, partial gWf / gcf) -> coupling backward of the step
+ *                         below (g_a3, g_z2, partial bias3 / logs3 sums)]
+ *   -- or, where the pixel tiles are whole images (no halo rows: nfk_run2d_fused_ok), ONE launch that walks all K steps
+ *   with the gradient tile in LDS between them --, then
+ *   per level ONE launch with the 3 K weight-gradient GEMMs and the 2 K ActNorm sums (few, long split-K ranges instead of
+ *   16 short ones per step), and ONE launch with every reduction (split slabs, partial rows) into the parameter gradients.
+ * Everything the forward kept is addressed as base + k * stride (k = step index in forward order), as nfk_fused_run does;
+ * `steps` / `grads` are DEVICE arrays, `host_steps` a HOST copy of `steps` (`first` = its element 0).  g_ext (optional) is added to g_out; steps below the
+ * last one take no external gradient (a caller with hint gradients inside the level calls per sub-run: k_lo / k_hi).
+ * mix_part of step k receives nfk_level_bwd_parts(first) partial slabs (nfk_prep_grad.nparts). */
+typedef struct nfk_level_grads {
+  float *g_w1, *g_b1, *g_l1, *g_w2, *g_b2, *g_l2, *g_w3, *g_bias3, *g_l3;
+  float *mix_part;
+} nfk_level_grads;
+typedef struct nfk_level_bwd {
+  const nfk_step2d *steps;
+  const nfk_level_grads *grads;
+  int32_t nsteps, ldx0;
+  const float *x0;                               /* input of step 0: [M][ldx0] */
+  const float *zout; int64_t zout_stride;        /* outputs of the steps: the input of step k >= 1 is zout + (k-1) * stride */
+  const float *zsave; int64_t zsave_stride;      /* mixed z                                  (floats) */
+  const float *hsave; int64_t hsave_stride;      /* (shift | scale) of the coupling tail      (floats) */
+  const void *h1save, *h2save; int64_t h_stride; /* [M][hidden] bf16                          (elements) */
+  const void *masks; int64_t mask_stride;        /* ReLU masks + conv1's im2col rows          (bytes) */
+  const float *g_out, *g_ext, *g_ld;             /* wrt the output of step k_hi (g_ext may be NULL), wrt the log-det */
+  float *g_x;                                    /* out: wrt the input of step k_lo */
+  float *ws;                                     /* nfk_level_bwd_ws_floats(first, nsteps) floats */
+  int32_t k_lo, k_hi;                            /* steps k_hi, k_hi - 1, ..., k_lo are walked (0 <= k_lo <= k_hi < nsteps) */
+  int32_t multi;                                 /* 1: one launch for all of them where the geometry allows, 0: one per step */
+  nfk_aux *aux;                                  /* optional: the two per-level launches go to this stream (join: nfk_aux_join) */
+} nfk_level_bwd;
+int nfk_level_bwd_ok(const nfk_step2d *first);        /* 1: nfk_level2d_bwd covers this geometry */
+int nfk_level_bwd_parts(const nfk_step2d *first);     /* partial (gWf, gcf) slabs per step = workgroups of the step launch */
+size_t nfk_level_bwd_ws_floats(const nfk_step2d *first, int nsteps);
+int nfk_level2d_bwd(const nfk_level_bwd *lv, const nfk_step2d *host_steps, void *stream);
 /* diagnostic: leave parts of the fused backward's weight-gradient launch out, to time the others (bit 0: ActNorm sums,
  * 1: conv2, 2: conv3, 3: conv1); gradients are then wrong.  0 = off */
 void nfk_debug_triple_parts(int skip_mask);

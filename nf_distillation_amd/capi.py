@@ -64,6 +64,22 @@ class FusedRun(C.Structure):
                 ("masksave", c_fp), ("mask_stride", C.c_int64), ("ldpart", c_fp)]
 
 
+class LevelGrads(C.Structure):
+    """nfk_level_grads: where the parameter gradients of one step of a level accumulate."""
+    _fields_ = [("g_w1", c_fp), ("g_b1", c_fp), ("g_l1", c_fp), ("g_w2", c_fp), ("g_b2", c_fp),
+                ("g_l2", c_fp), ("g_w3", c_fp), ("g_bias3", c_fp), ("g_l3", c_fp), ("mix_part", c_fp)]
+
+
+class LevelBwd(C.Structure):
+    """nfk_level_bwd (include/nfk.h): the backward of a run of FlowSteps of one level."""
+    _fields_ = [("steps", c_fp), ("grads", c_fp), ("nsteps", C.c_int32), ("ldx0", C.c_int32), ("x0", c_fp),
+                ("zout", c_fp), ("zout_stride", C.c_int64), ("zsave", c_fp), ("zsave_stride", C.c_int64),
+                ("hsave", c_fp), ("hsave_stride", C.c_int64), ("h1save", c_fp), ("h2save", c_fp), ("h_stride", C.c_int64),
+                ("masks", c_fp), ("mask_stride", C.c_int64), ("g_out", c_fp), ("g_ext", c_fp), ("g_ld", c_fp),
+                ("g_x", c_fp), ("ws", c_fp), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("multi", C.c_int32),
+                ("pad_", C.c_int32), ("aux", c_fp)]
+
+
 class Step2dPending(C.Structure):
     """nfk_step2d_pending: the slab / partial-row reductions a merged weight-gradient launch leaves to the next call."""
     _fields_ = [("valid", C.c_int32), ("pad_", C.c_int32), ("blob", C.c_uint64 * 40)]
@@ -169,6 +185,10 @@ _PROTOS = {
     "nfk_step2d_bwd_ga_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_step2d_bwd_wslab_floats": (u64, [C.POINTER(Step2d)]),
     "nfk_aux_join": (i32, [vp, vp]),
+    "nfk_level_bwd_ok": (i32, [C.POINTER(Step2d)]),
+    "nfk_level_bwd_parts": (i32, [C.POINTER(Step2d)]),
+    "nfk_level_bwd_ws_floats": (u64, [C.POINTER(Step2d), i32]),
+    "nfk_level2d_bwd": (i32, [C.POINTER(LevelBwd), C.POINTER(Step2d), vp]),
     "nfk_step2d_fused_bwd_ok": (i32, [C.POINTER(Step2d)]),
     "nfk_fused_bwd_set_stamps": (None, [vp]),
     "nfk_debug_triple_parts": (None, [i32]),

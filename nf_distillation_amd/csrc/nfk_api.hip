@@ -636,6 +636,98 @@ size_t nfk_step2d_bwd_wslab_floats(const nfk_step2d* s) {
   const StepBwdWs L = step_bwd_layout(s);
   return (L.x3 - L.wslab) + align4((size_t)L.mb2 * 2 * s->hidden) + align4((size_t)L.mb1 * 2 * s->hidden);   // slabs, col2, col1
 }
+// ------------------------------------------------------------------------------------------
+// backward of a whole level (include/nfk.h: nfk_level_bwd)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct LevelWs {
+  size_t gz0, gz1, tailpart, ga, wslab, total;
+  size_t ga_stride, o_ga2, o_ga1, o_x3;            // inside a step's gradient block
+  size_t wslab_stride, o_s2, o_s1, o_col2, o_col1;   // inside a step's slab block
+  int K3p, K1p, nparts;
+};
+LevelWs level_ws_layout(const nfk_step2d* s, int nsteps) {
+  LevelWs w;
+  const size_t M = (size_t)s->B * s->H * s->W, hid = (size_t)s->hidden;
+  w.K3p = fusedb_k3p(*s); w.K1p = fused2_k1p(*s); w.nparts = actnorm_sum_parts((int)M);
+  w.o_ga2 = align4(M * s->Cout);
+  w.o_ga1 = w.o_ga2 + align4((M * hid + 1) / 2);
+  w.o_x3 = w.o_ga1 + align4((M * hid + 1) / 2);
+  w.ga_stride = w.o_x3 + align4((M * w.K3p + 1) / 2);
+  const size_t S = NFK_LEVEL_MAX_SPLITS;
+  w.o_s2 = align4(S * w.K3p * hid);
+  w.o_s1 = w.o_s2 + align4(S * hid * hid);
+  w.o_col2 = w.o_s1 + align4(S * hid * w.K1p);
+  w.o_col1 = w.o_col2 + align4((size_t)w.nparts * 2 * hid);
+  w.wslab_stride = w.o_col1 + align4((size_t)w.nparts * 2 * hid);
+  size_t o = 0;
+  w.gz0 = o; o += align4(M * s->C);
+  w.gz1 = o; o += align4(M * s->C);
+  w.tailpart = o; o += align4((size_t)nsteps * 256 * 2 * s->Cout);
+  w.ga = o; o += (size_t)nsteps * w.ga_stride;
+  w.wslab = o; o += (size_t)nsteps * w.wslab_stride;
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int nfk_level_bwd_ok(const nfk_step2d* first) {
+  if (!first || !first->bf16 || first->hidden != 512 || first->B > 256) return 0;
+  return fusedb_level_ok(*first);
+}
+int nfk_level_bwd_parts(const nfk_step2d* first) { return nfk_level_bwd_ok(first) ? fusedb_level_grid(*first) : 0; }
+size_t nfk_level_bwd_ws_floats(const nfk_step2d* first, int nsteps) {
+  return (first && nsteps > 0) ? level_ws_layout(first, nsteps).total : 0;
+}
+
+int nfk_level2d_bwd(const nfk_level_bwd* lv, const nfk_step2d* host_steps, void* stream) {
+  hipStream_t st = S_(stream);
+  if (!lv || !host_steps || lv->nsteps < 1 || lv->k_lo < 0 || lv->k_hi >= lv->nsteps || lv->k_lo > lv->k_hi) return NFK_ERR_ARG;
+  const nfk_step2d* s = host_steps;   // dimensions of the level
+  if (!nfk_level_bwd_ok(s)) return NFK_ERR_ARG;
+  if (!lv->steps || !lv->grads || !lv->x0 || !lv->zsave || !lv->hsave || !lv->h1save || !lv->h2save || !lv->masks ||
+      !lv->g_out || !lv->g_x || !lv->ws || (lv->nsteps > 1 && !lv->zout))
+    return NFK_ERR_ARG;
+  const int B = s->B, HW = s->H * s->W, M = B * HW, C = s->C, Cout = s->Cout;
+  const LevelWs L = level_ws_layout(s, lv->nsteps);
+  float* ws = lv->ws;
+  const int kh = lv->k_hi;
+  // 1. coupling backward of the top step (the steps below get theirs from the launch of the step above)
+  CouplingBwdArgs cb{};
+  cb.gout = lv->g_out; cb.ldg = C; cb.gext = lv->g_ext; cb.ldge = C; cb.gld = lv->g_ld;
+  cb.z = lv->zsave + (long)kh * lv->zsave_stride; cb.ldz = C; cb.h = lv->hsave + (long)kh * lv->hsave_stride;
+  cb.es3 = host_steps[kh].es3; cb.ga3 = ws + L.ga + (size_t)kh * L.ga_stride;
+  cb.gz = ws + ((kh & 1) ? L.gz1 : L.gz0); cb.ldgz = C;
+  cb.part = ws + L.tailpart + (size_t)kh * 256 * 2 * Cout;
+  cb.HW = HW; cb.C = C; cb.Cout = Cout; cb.additive = s->additive;
+  cb.tiles = coupling_bwd_tiles(B, HW);
+  if (B * cb.tiles > 256) return NFK_ERR_ARG;
+  NFK_TRY(launch_coupling_bwd(cb, B, st));
+  // 2. the steps' launches (or the one launch of the run)
+  FusedLevelCall fc{};
+  fc.lv = *lv; fc.first = *s;
+  fc.gz[0] = ws + L.gz0; fc.gz[1] = ws + L.gz1; fc.tailpart = ws + L.tailpart;
+  fc.ga = ws + L.ga; fc.ga_stride = (long)L.ga_stride; fc.o_ga2 = (long)L.o_ga2; fc.o_ga1 = (long)L.o_ga1; fc.o_x3 = (long)L.o_x3;
+  int grid = 0;
+  NFK_TRY(fusedb_level_launch(fc, st, &grid));
+  // 3. all weight-gradient GEMMs + ActNorm sums, then every reduction into the parameter gradients
+  hipStream_t wst = st;
+  nfk_aux* const ax = lv->aux;
+  if (ax && ax->stream != st) { fork_to_aux(ax, st, 0); wst = ax->stream; }
+  LevelWgradArgs wa{};
+  wa.steps = lv->steps; wa.grads = lv->grads; wa.k_lo = lv->k_lo; wa.k_hi = kh;
+  wa.B = B; wa.H = s->H; wa.W = s->W; wa.M = M; wa.hid = s->hidden; wa.Cout = Cout; wa.Ch = C / 2; wa.K3p = L.K3p; wa.K1p = L.K1p;
+  wa.S = level_wgrad_splits(M, s->hidden, L.K3p, L.K1p, kh - lv->k_lo + 1);
+  wa.ga = ws + L.ga; wa.ga_stride = (long)L.ga_stride; wa.o_ga2 = (long)L.o_ga2; wa.o_ga1 = (long)L.o_ga1; wa.o_x3 = (long)L.o_x3;
+  wa.h1 = lv->h1save; wa.h2 = lv->h2save; wa.h_stride = lv->h_stride;
+  wa.masks = reinterpret_cast<const unsigned char*>(lv->masks); wa.mask_stride = lv->mask_stride;
+  wa.o_x1 = (long)2 * M * (s->hidden / 8);
+  wa.wslab = ws + L.wslab; wa.wslab_stride = (long)L.wslab_stride; wa.o_s2 = (long)L.o_s2; wa.o_s1 = (long)L.o_s1;
+  wa.o_col2 = (long)L.o_col2; wa.o_col1 = (long)L.o_col1;
+  wa.tailpart = ws + L.tailpart; wa.rows_top = B * cb.tiles; wa.rows = grid;
+  return level_wgrad_launch(wa, wst, wst);
+}
+
 void nfk_debug_triple_parts(int skip_mask) { triple_wgrad_debug_skip(skip_mask); }
 void nfk_fused_bwd_set_stamps(void* buf) { g_bwd_stamps = reinterpret_cast<unsigned long long*>(buf); }
 int nfk_step2d_fused_bwd_ok(const nfk_step2d* s) { return (s->bf16 && fusedb_grid(*s) > 0) ? 1 : 0; }

@@ -33,15 +33,28 @@ typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
 
 struct FBArgs {
-  FusedBwdCall c;
+  FusedBwdCall c;        // one step, stand-alone: the call.  Level mode (LV): c.s = the level's first step (dimensions)
   int R, TS, halo;       // rows per tile, samples per tile, 1 if the tile needs halo rows
   int lw, lrw, lhw;      // log2(W), log2(R*W), log2(RH*W) (the last only meaningful when TS > 1)
+  // ---- level mode (nfk_level2d_bwd): the launch walks steps k_hi .. k_lo (one step per launch unless MULTI)
+  nfk_level_bwd lv;
+  int k_hi, k_lo;
+  float* gz[2];          // [M][C] rows of dL/dz (mixed tensor), step k in gz[k & 1]: written by the coupling backward
+  float* tailpart;       // [nsteps][256][2][Cout] partial (sum g_a3, 3 sum g_h h) rows of the coupling backward
+  float* ga;             // per-step blocks of ga_stride floats: g_a3 fp32 | g_a2 bf16 | g_a1 bf16 | dgrad3's im2col rows bf16
+  long ga_stride, o_ga2, o_ga1, o_x3;   // (offsets in floats)
 };
 
 struct FBGeom {
   int RH, RZ, P_h, MT32, K3, K3M, K3p, X3S, NTD;
-  size_t oG3, oPar, oX3, oImg, oZero, total;
+  size_t oG3, oPar, oX3, oImg, oZero, oGZ, total;
 };
+// level mode: floats of the epilogue's scratch (it lives in the im2col region, dead after dgrad3):
+//   GZ' / XIN / GX tiles [npx][C + 1], Wf [C][Cp], the coupling backward's per-group column sums [256 / C2][4][C2]
+__host__ __device__ static inline size_t fb_epi_floats(int C, int npx) {
+  const int Cp = (C + 3) & ~3, C2 = C - C / 2;
+  return (size_t)2 * npx * (C + 1) + (size_t)C * Cp + (size_t)(256 / (C2 > 0 ? C2 : 1)) * 4 * C2;
+}
 
 __host__ __device__ static inline FBGeom fb_geom(const nfk_step2d& s, int R, int TS, int halo) {
   FBGeom g;
@@ -63,7 +76,13 @@ __host__ __device__ static inline FBGeom fb_geom(const nfk_step2d& s, int R, int
   o = (o + 15) & ~size_t(15);
   g.oImg = o; o += (size_t)g.MT32 * 32 * 1024;
   g.oZero = o; o += 3 * 256 + 16;   // sixteen zero bytes per 128-channel chunk, 256 bytes apart (see nfk_fused2.hip)
+  g.oGZ = o;                        // level mode only: the tile's rows of dL/dz [TS * R * W][C + 1] fp32 (fb_geom_lv)
   g.total = o;
+  return g;
+}
+__host__ __device__ static inline FBGeom fb_geom_lv(const nfk_step2d& s, int R, int TS, int halo) {
+  FBGeom g = fb_geom(s, R, TS, halo);
+  g.total = g.oGZ + (size_t)TS * R * s.W * (s.C + 1) * 4;
   return g;
 }
 
@@ -85,23 +104,56 @@ __device__ __forceinline__ int fb_img_off(int px, int slot) {
 
 // MO: output pixels per tile in units of 16 -- 4 (64 pixels) or, on tiny images with a small grid (CIFAR level 3), 2 / 1:
 // more workgroups, each with a smaller share of everything but the weight stream (as nfk_fused2.hip's runs of steps).
-template <int MT32, int NTD, int K3M, int MO = 4>
+//
+// LV ("level mode", nfk_level2d_bwd): the launch belongs to the backward of a whole level.  Per-step pointers come from the
+// device arrays lv.steps / lv.grads (scalar loads), per-step buffers are base + k * stride, and the kernel also does what
+// the channel-mix launch did for the step: on the tile's own pixels
+//     g_z = [dL/dz1 + dgrad1 | dL/dz2]  ->  g_x = Wf^T g_z, partial (g_z x^T, sum g_z) for nfk_prep_bwd
+//     -> coupling backward of the step BELOW (k - 1): g_a3, dL/dz of that step, its partial (bias3, logs3) row
+// so that a step's backward is ONE launch.  MULTI (tiles that are whole images: no halo rows): the launch walks steps
+// k_hi .. k_lo; g_a3 and dL/dz of the next step stay in LDS, only what the weight-gradient GEMMs read goes to HBM.
+// The arithmetic per element is that of chanmix_body / coupling_bwd_kernel (nfk_tail.h, nfk_flow.hip).
+template <int MT32, int NTD, int K3M, int MO = 4, bool LV = false, bool MULTI = false>
 __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   static_assert(MO == 4 || ((MO == 2 || MO == 1) && MT32 == 1), "small tiles: whole tiny images only");
+  static_assert(!MULTI || LV, "runs of steps exist in level mode only");
+  typedef const __attribute__((address_space(4))) nfk_step2d CStep;        // scalar (constant-memory) loads
+  typedef const __attribute__((address_space(4))) nfk_level_grads CGrads;
+#define FBS(f) (LV ? sp->f : a.c.s.f)
   constexpr int HID = 512;
   constexpr int NPX = 16 * MO;   // output pixels of a tile
   constexpr int MT_O = MO;       // output m-tiles of 16 (dgrad1 uses 16x16x32)
   extern __shared__ __attribute__((aligned(16))) char smem_fb[];
-  const nfk_step2d& s = a.c.s;
-  const int W = s.W, H = s.H, Ch = s.C / 2, Cout = s.Cout, HW = H * W;
-  const int R = a.R, TS = a.TS, halo = a.halo, lw = a.lw, lrw = a.lrw, lhw = a.lhw;
-  const FBGeom g = fb_geom(s, R, TS, halo);
+  const nfk_step2d& s = a.c.s;   // dimensions (the same for every step of a level); per-step POINTERS go through FBS
+  const int k_first = LV ? a.k_hi : 0, k_last = LV ? (MULTI ? a.k_lo : a.k_hi) : 0;
+  for (int k = k_first; k >= k_last; --k) {
+  // (a run of steps: thread index and dimensions pass through an empty asm once per step so that what derives from them
+  //  is computed where it is used instead of being hoisted out of the step loop and kept live across it: nfk_fused2.hip)
+  int tid_ = threadIdx.x, W_ = s.W, H_ = s.H, C_ = s.C, Cout_ = s.Cout, R_ = a.R, TS_ = a.TS;
+  if (MULTI) {
+    asm volatile("" : "+v"(tid_));
+    asm volatile("" : "+s"(W_), "+s"(H_), "+s"(C_), "+s"(Cout_), "+s"(R_), "+s"(TS_));
+  }
+  const int W = W_, H = H_, C = C_, Ch = C / 2, Cout = Cout_, HW = H * W;
+  const int R = R_, TS = TS_, halo = a.halo, lw = a.lw, lrw = a.lrw, lhw = a.lhw;
+  nfk_step2d sd;   // the dimensions fb_geom reads
+  sd.W = W; sd.H = H; sd.C = C; sd.Cout = Cout; sd.hidden = HID; sd.B = s.B;
+  const FBGeom g = LV ? fb_geom_lv(sd, R, TS, halo) : fb_geom(sd, R, TS, halo);
+  CStep* sp = LV ? (CStep*)(a.lv.steps + k) : nullptr;
+  // this step's buffers: the call's (stand-alone) or base + k * stride (level mode)
+  float* const gablk = LV ? a.ga + (long)k * a.ga_stride : nullptr;
+  const float* const c_ga3 = LV ? gablk : a.c.ga3;
+  const unsigned char* const c_masks =
+      LV ? reinterpret_cast<const unsigned char*>(a.lv.masks) + (long)k * a.lv.mask_stride : a.c.masks;
+  void* const c_ga2 = LV ? (void*)(gablk + a.o_ga2) : a.c.ga2;
+  void* const c_ga1 = LV ? (void*)(gablk + a.o_ga1) : a.c.ga1;
+  void* const c_x3save = LV ? (void*)(gablk + a.o_x3) : a.c.x3save;
   float* G3 = reinterpret_cast<float*>(smem_fb + g.oG3);
   float* Pe2 = reinterpret_cast<float*>(smem_fb + g.oPar);
   float* Pe1 = Pe2 + HID;
   char* X3 = smem_fb + g.oX3;
   char* IMG = smem_fb + g.oImg;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = tid_, lane = tid & 63, wid = tid >> 6;
   const int l32 = lane & 31, hi = lane >> 5;      // 32x32x16 operand roles: row / k-half
   const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 operand roles (dgrad1)
 
@@ -112,7 +164,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   const int row0 = tile * R;
   const int zh = 2 * halo;
   auto stamp = [&](int i) {
-    if (a.c.stamps && tid == 0) a.c.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
+    if (!LV && a.c.stamps && tid == 0) a.c.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
   };
   stamp(0);
 
@@ -122,7 +174,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   constexpr int W3R = (K3M >= 28) ? 1 : ((K3M >= 16) ? 2 : 4);   // register ring: tiles of 32 output channels held ahead
                                                                   // (1: every fragment is reloaded in place right after its use)
   bf16x8f w3[W3R][K3M];
-  const __amdgpu_buffer_rsrc_t r3 = fb_rsrc(s.wg3, (unsigned)HID * g.K3p * 2);
+  const __amdgpu_buffer_rsrc_t r3 = fb_rsrc(FBS(wg3), (unsigned)HID * g.K3p * 2);
   auto load_w3 = [&](int j, bf16x8f (&f)[K3M]) {   // row tile (32 channels) swid*4 + j
     const int soff = (swid * 4 + j) * K3M * 1024;
 #pragma unroll
@@ -153,7 +205,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   {
     constexpr unsigned FB_OOB = 0x80000000u;
     const long msz = (long)s.B * HW * (HID / 8);
-    const __amdgpu_buffer_rsrc_t rm1 = fb_rsrc(a.c.masks, (unsigned)msz), rm2 = fb_rsrc(a.c.masks + msz, (unsigned)msz);
+    const __amdgpu_buffer_rsrc_t rm1 = fb_rsrc(c_masks, (unsigned)msz), rm2 = fb_rsrc(c_masks + msz, (unsigned)msz);
 #pragma unroll
     for (int mt = 0; mt < MT32; ++mt) {
       const int ph = mt * 32 + l32;
@@ -171,17 +223,55 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     const int rowlen = W * Cout, per_s = g.RZ * rowlen, nx = TS * per_s;
     const int lo = (TS == 1) ? max(0, zh - row0) * rowlen : 0;                                     // elements inside the image
     const int hi_e = (TS == 1) ? min(g.RZ, H - row0 + zh) * rowlen : min(s.B - b0, TS) * per_s;    // ... and the batch
-    const float* gb = a.c.ga3 + ((long)b0 * HW + (long)(row0 - zh) * W) * Cout;   // rows are contiguous: [pixel][Cout]
-    float greg[GMAX];
+    const float* gb = c_ga3 + ((long)b0 * HW + (long)(row0 - zh) * W) * Cout;   // rows are contiguous: [pixel][Cout]
+    const bool stage = !MULTI || k == k_first;   // (later steps of a run: the epilogue of the step above left both tiles in LDS)
+    float greg[GMAX], zreg[GMAX];
+    if (stage) {
 #pragma unroll
-    for (int i = 0; i < GMAX; ++i) greg[i] = gb[min(max(tid + 256 * i, lo), hi_e - 1)];   // clamped: unconditional loads
-    const float e2a = s.es2[tid], e2b = s.es2[tid + 256], e1a = s.es1[tid], e1b = s.es1[tid + 256];
+      for (int i = 0; i < GMAX; ++i) greg[i] = gb[min(max(tid + 256 * i, lo), hi_e - 1)];   // clamped: unconditional loads
+      if (LV) {
+        // the tile's own rows of dL/dz: element e = (pixel of the tile, channel).  Second half: the coupling backward's
+        // g_z2 (gz[k & 1]); first half: the gradient wrt the step's output -- g_out (+ g_ext) for the first step walked,
+        // else what the launch above stored in the same rows of gz
+        const int per_t = R * W * C, nz = min(s.B - b0, TS) * per_t;   // tile pixels are contiguous in [M]: rows row0.. of b0..
+        const long e0 = ((long)b0 * HW + (long)row0 * W) * C;
+        const float* zsrc = a.gz[k & 1] + e0;
+        const bool top = k == a.lv.k_hi;
+        const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+#pragma unroll
+        for (int i = 0; i < GMAX; ++i) {
+          const int e = min(tid + 256 * i, nz - 1);
+          const int c = e - (int)__umulhi((unsigned)e, mC) * C;
+          float v = zsrc[e];
+          if (top && c < Ch) {
+            v = a.lv.g_out[e0 + e];
+            if (a.lv.g_ext) v += a.lv.g_ext[e0 + e];
+          }
+          zreg[i] = (tid + 256 * i < nz) ? v : 0.f;
+        }
+      }
+    }
+    const float e2a = FBS(es2)[tid], e2b = FBS(es2)[tid + 256], e1a = FBS(es1)[tid], e1b = FBS(es1)[tid + 256];
 #pragma unroll
     for (int j = 0; j < W3R; ++j) load_w3(j, w3[j]);
+    if (stage) {
 #pragma unroll
-    for (int i = 0; i < GMAX; ++i) {
-      const int e = tid + 256 * i;
-      if (e < nx) G3[e] = (e >= lo && e < hi_e) ? greg[i] : 0.f;
+      for (int i = 0; i < GMAX; ++i) {
+        const int e = tid + 256 * i;
+        if (e < nx) G3[e] = (e >= lo && e < hi_e) ? greg[i] : 0.f;
+      }
+      if (LV) {
+        float* GZl = reinterpret_cast<float*>(smem_fb + g.oGZ);   // [tile pixel][C + 1]
+        const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+#pragma unroll
+        for (int i = 0; i < GMAX; ++i) {
+          const int e = tid + 256 * i;
+          if (e < NPX * C) {
+            const int po = (int)__umulhi((unsigned)e, mC);
+            GZl[po * (C + 1) + (e - po * C)] = zreg[i];
+          }
+        }
+      }
     }
     Pe2[tid] = e2a; Pe2[tid + 256] = e2b; Pe1[tid] = e1a; Pe1[tid + 256] = e1b;
     if (tid < 16) reinterpret_cast<unsigned*>(smem_fb + g.oZero + (tid >> 2) * 256)[tid & 3] = 0u;
@@ -234,11 +324,11 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   }
   __syncthreads();
   stamp(2);
-  if (a.c.x3save) {
+  if (c_x3save) {
     // the im2col rows of the tile's own pixels, bf16 [M][K3p]: X3[m][tap * Cout + co] = g_a3[m + d(tap)][co] is, with the
     // taps flipped, the P operand of conv3's weight gradient as a plain pixel-major GEMM (sum_m X3[m][(8 - tap) Cout + co]
     // h2[m][ci]) -- instead of nine shifted passes over the 512-wide h2
-    __bf16* x3g = reinterpret_cast<__bf16*>(a.c.x3save);
+    __bf16* x3g = reinterpret_cast<__bf16*>(c_x3save);
     constexpr int PPR = K3M * 2;   // 16-byte pieces per row
     for (int p = tid; p < NPX * PPR; p += 256) {
       const int po = p / PPR, slot = p % PPR;
@@ -273,7 +363,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   };
 
   // ------------------------------------------------------------------ 2. dgrad3 -> g_a2 in the image
-  const __amdgpu_buffer_rsrc_t r2 = fb_rsrc(s.wg2, (unsigned)HID * HID * 2);
+  const __amdgpu_buffer_rsrc_t r2 = fb_rsrc(FBS(wg2), (unsigned)HID * HID * 2);
   constexpr int NCH = 4, RD = 8;             // dgrad2: channel tiles per wave, W2^T register ring (RD k-steps x NCH)
   bf16x8f w2r[RD][NCH];
   int w2s[NCH];
@@ -329,15 +419,17 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   }
   __syncthreads();
   stamp(3);
-  save_rows(reinterpret_cast<__bf16*>(a.c.ga2));
+  save_rows(reinterpret_cast<__bf16*>(c_ga2));
   stamp(4);
 
   // ------------------------------------------------------------------ 3. dgrad2: ONE pass over k (see nfk_fused2.hip, conv2)
-  const __amdgpu_buffer_rsrc_t r1 = fb_rsrc(s.wg1, (unsigned)NTD * 16 * 9 * HID * 2);
+  const __amdgpu_buffer_rsrc_t r1 = fb_rsrc(FBS(wg1), (unsigned)NTD * 16 * 9 * HID * 2);
   constexpr int Kp1 = 9 * HID;
   constexpr int D1 = (NTD == 1 && MT32 == 2) ? 4 : 2;   // dgrad1's weight ring: chunks of 128 channels held ahead (it is
                                                         // requested while dgrad2's 4 x MT32 accumulator tiles are live)
   bf16x8f w1[D1][9][NTD];
+  constexpr int EXMAX = LV ? 12 : 1, EWMAX = LV ? 9 : 1;   // level mode: NPX * C <= 3072, C * C <= 2304 (checked on the host)
+  float exreg[EXMAX], ewreg[EWMAX];
   auto load_w1 = [&](int slot, int nc, int tap) {   // k-step (of 32) tap*16 + nc*4 + swid of every row tile
 #pragma unroll
     for (int nt = 0; nt < NTD; ++nt)
@@ -381,6 +473,24 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     for (int c = 0; c < D1; ++c)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) load_w1(c, c, tap);
+    if (LV) {
+      // level mode: the epilogue's operands -- the step's input rows on the tile (x_in: the other factor of the partial
+      // g_z x^T) and Wf -- are requested here too and parked in the dead im2col region behind the epilogue below
+      const float* xin = k == 0 ? a.lv.x0 : a.lv.zout + (long)(k - 1) * a.lv.zout_stride;
+      const int ldxi = k == 0 ? a.lv.ldx0 : C;
+      const int nzp = min(s.B - b0, TS) * R * W;   // valid pixels of the tile
+      const long m0 = (long)b0 * HW + (long)row0 * W;
+      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+      const float* Wfp = FBS(Wf);
+#pragma unroll
+      for (int i = 0; i < EXMAX; ++i) {
+        const int e = min(tid + 256 * i, nzp * C - 1);
+        const int po = (int)__umulhi((unsigned)e, mC);
+        exreg[i] = xin[(m0 + po) * ldxi + (e - po * C)];
+      }
+#pragma unroll
+      for (int i = 0; i < EWMAX; ++i) ewreg[i] = Wfp[min(tid + 256 * i, C * C - 1)];
+    }
     __syncthreads();   // every wave is done reading g_a2: g_a1 takes its place in the image (same layout)
     stamp(6);
     char* imw[MT32];
@@ -400,7 +510,34 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   }
   __syncthreads();
   stamp(7);
-  save_rows(reinterpret_cast<__bf16*>(a.c.ga1));
+  // level-mode epilogue scratch, in the im2col region (dead since dgrad3)
+  const int XS = C + 1, Cp4 = (C + 3) & ~3;
+  float* const XIl = reinterpret_cast<float*>(X3);   // [NPX][XS]  x_in tile
+  float* const GXl = XIl + NPX * XS;                 // [NPX][XS]  g_x tile
+  float* const Wl = GXl + NPX * XS;                  // [C][Cp4]   Wf as [in][out]
+  float* const Al = Wl + C * Cp4;                    // [256 / C2][4][C2] column sums of the coupling backward
+  float* const GZl = reinterpret_cast<float*>(smem_fb + g.oGZ);   // [NPX][XS] dL/dz on the tile
+  if (LV) {
+    const int nzp = min(s.B - b0, TS) * R * W;
+    const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+#pragma unroll
+    for (int i = 0; i < EXMAX; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NPX * C) {
+        const int po = (int)__umulhi((unsigned)e, mC);
+        XIl[po * XS + (e - po * C)] = (e < nzp * C) ? exreg[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EWMAX; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < C * C) {
+        const int r = (int)__umulhi((unsigned)idx, mC);
+        Wl[r * Cp4 + (idx - r * C)] = ewreg[i];   // Wm[r][q]: in = r, out = q (chanmix_body, trans)
+      }
+    }
+  }
+  save_rows(reinterpret_cast<__bf16*>(c_ga1));
   stamp(8);
 
   // ------------------------------------------------------------------ 4. dgrad1 over the wave's K-slices of the g_a1 image
@@ -470,15 +607,165 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       *reinterpret_cast<f32x4*>(R3 + ((wid * NPX + mo * 16 + r16) * NP + nt * 16 + q4 * 4)) = acc1[nt][mo];
   __syncthreads();
   const unsigned mCh = 0xFFFFFFFFu / (unsigned)Ch + 1u;
-  for (int idx = tid; idx < NPX * Ch; idx += 256) {
-    const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
-    const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
-    const int b = b0 + sm;
-    if (b >= s.B) continue;
-    const float* p = R3 + po * NP + n;
-    a.c.d1[((long)b * HW + (row0 + rr) * W + xx) * Ch + n] = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
+  if (!LV) {
+    for (int idx = tid; idx < NPX * Ch; idx += 256) {
+      const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
+      const int sm = po >> lrw, rem = po & ((1 << lrw) - 1), rr = rem >> lw, xx = rem & (W - 1);
+      const int b = b0 + sm;
+      if (b >= s.B) continue;
+      const float* p = R3 + po * NP + n;
+      a.c.d1[((long)b * HW + (row0 + rr) * W + xx) * Ch + n] = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
+    }
+    stamp(10);
+  } else {
+    // ---------------------------------------------------------------- 6. level mode: channel-mix backward on the tile
+    const int C2n = C - Ch, Gn = 256 / C2n, G4 = Cp4 / 4;
+    const bool below = k > a.lv.k_lo;   // the coupling backward of step k - 1 rides along
+    CStep* spn = (CStep*)(a.lv.steps + (below ? k - 1 : k));
+    const int jn = tid % C2n, gn = tid / C2n;
+    const long mt0 = (long)b0 * HW + (long)row0 * W;   // first pixel of the tile (its pixels are contiguous in [M])
+    const int nzp = min(s.B - b0, TS) * R * W;         // ... and how many of them exist
+    // operands of the coupling backward below: (shift | scale) rows and z2 of step k - 1, requested before the mat-vec
+    constexpr int CPF = 8;   // pixels per thread: NPX / Gn <= 7 (checked on the host)
+    float ch0[CPF], ch1[CPF], cz[CPF];
+    if (below && gn < Gn) {
+      const float* hn = a.lv.hsave + (long)(k - 1) * a.lv.hsave_stride + mt0 * Cout;
+      const float* zn = a.lv.zsave + (long)(k - 1) * a.lv.zsave_stride + mt0 * C;
+#pragma unroll
+      for (int e = 0; e < CPF; ++e) {
+        const int pp = min(gn + e * Gn, nzp - 1);
+        if (s.additive) { ch0[e] = hn[pp * Cout + jn]; ch1[e] = 0.f; cz[e] = 0.f; }
+        else { ch0[e] = hn[pp * Cout + 2 * jn]; ch1[e] = hn[pp * Cout + 2 * jn + 1]; cz[e] = zn[pp * C + Ch + jn]; }
+      }
+    }
+    // g_z1 = (dL/dz1 of the step's output) + dgrad1, the four waves' partial sums in the order the stand-alone kernel adds them
+    for (int idx = tid; idx < NPX * Ch; idx += 256) {
+      const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
+      const float* p = R3 + po * NP + n;
+      const float d = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
+      if (po < nzp) GZl[po * XS + n] += d;
+    }
+    __syncthreads();
+    // g_x = Wf^T g_z: thread (pixel p of a pass, outputs 4 og .. 4 og + 3), input channels ascending (chanmix_body)
+    {
+      const int TP = 256 / G4 < NPX ? (256 / G4) : NPX;
+      const int p = tid / G4, og = tid - p * G4, o = og * 4;
+      float* gxo = (k == a.lv.k_lo) ? a.lv.g_x : nullptr;
+      if (p < TP)
+        for (int pp = p; pp < NPX; pp += TP) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const float* xr = GZl + pp * XS;
+          for (int c = 0; c < C; ++c) {
+            const float xv = xr[c];
+            const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp4 + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) GXl[pp * XS + o + r] = acc[r];
+          if (gxo && pp < nzp) *reinterpret_cast<f32x4*>(gxo + (mt0 + pp) * C + o) = acc;   // C % 4 == 0 (host check)
+        }
+    }
+    // partial (g_z x_in^T, sum g_z) of this workgroup: one slab of the step's mix_part
+    {
+      const int E = C * C + C;
+      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+      float* part = ((CGrads*)(a.lv.grads + k))->mix_part + (long)blockIdx.x * E;
+      for (int idx = tid; idx < E; idx += 256) {
+        float sm_ = 0.f;
+        if (idx < C * C) {
+          const int o = (int)__umulhi((unsigned)idx, mC), c = idx - o * C;
+          for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o] * XIl[q * XS + c];
+        } else {
+          const int o = idx - C * C;
+          for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o];
+        }
+        part[idx] = sm_;
+      }
+    }
+    if (below) {
+      // -------------------------------------------------------------- 7. coupling backward of step k - 1 on the tile
+      __syncthreads();   // g_x is complete; the partial sums above are done with GZl (overwritten below in a run)
+      float* gan = a.ga + (long)(k - 1) * a.ga_stride + mt0 * Cout;     // g_a3 of step k - 1 (the weight gradients read it too)
+      float* gzn = a.gz[(k - 1) & 1] + mt0 * C;
+      const float* es3n = spn->es3;
+      float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
+      float gz2n[CPF];
+      if (gn < Gn) {
+#pragma unroll
+        for (int e = 0; e < CPF; ++e) {
+          const int pp = gn + e * Gn;
+          gz2n[e] = 0.f;
+          if (pp < NPX) {
+            float v0 = 0.f, v1 = 0.f;   // g_a3 entries (zero rows beyond the batch: dgrad's zero padding)
+            if (pp < nzp) {
+              const float g2 = GXl[pp * XS + Ch + jn];
+              if (s.additive) {
+                gz2n[e] = g2;
+                v0 = g2 * es3n[jn];
+                sb0 += v0; sl0 += g2 * ch0[e];
+              } else {
+                const float gl = a.lv.g_ld ? a.lv.g_ld[b0 + pp / (R * W)] : 0.f;
+                const float shf = ch0[e], sr = ch1[e];
+                const float sc = sigmoidf(sr + 2.f);
+                const float gshift = g2 * sc;
+                const float gsr = g2 * (cz[e] + shf) * sc * (1.f - sc) + gl * (1.f - sc);
+                gz2n[e] = gshift;
+                v0 = gshift * es3n[2 * jn]; v1 = gsr * es3n[2 * jn + 1];
+                sb0 += v0; sl0 += gshift * shf; sb1 += v1; sl1 += gsr * sr;
+              }
+              if (s.additive) gan[pp * Cout + jn] = v0;
+              else { gan[pp * Cout + 2 * jn] = v0; gan[pp * Cout + 2 * jn + 1] = v1; }
+              if (!MULTI) gzn[pp * C + Ch + jn] = gz2n[e];
+            }
+            if (MULTI) {   // the next step's g_a3 tile (whole images, no halo rows: tile pixel order)
+              if (s.additive) G3[pp * Cout + jn] = v0;
+              else { G3[pp * Cout + 2 * jn] = v0; G3[pp * Cout + 2 * jn + 1] = v1; }
+            }
+          }
+        }
+        float* row = Al + (long)gn * 4 * C2n;
+        row[jn] = sb0; row[C2n + jn] = sl0; row[2 * C2n + jn] = sb1; row[3 * C2n + jn] = sl1;
+      }
+      if (!MULTI) {   // dL/dz1 of step k - 1 = g_x's first half, beside g_z2 in the same rows
+        for (int idx = tid; idx < nzp * Ch; idx += 256) {
+          const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
+          gzn[po * C + n] = GXl[po * XS + n];
+        }
+      }
+      __syncthreads();
+      if (MULTI) {
+        if (gn < Gn) {
+#pragma unroll
+          for (int e = 0; e < CPF; ++e) {
+            const int pp = gn + e * Gn;
+            if (pp < NPX) GZl[pp * XS + Ch + jn] = gz2n[e];
+          }
+        }
+        for (int idx = tid; idx < NPX * Ch; idx += 256) {
+          const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
+          GZl[po * XS + n] = GXl[po * XS + n];
+        }
+      }
+      // one partial row per workgroup: (sum g_a3, 3 sum g_h h), groups added in fixed order
+      float* prow = a.tailpart + ((long)(k - 1) * 256 + blockIdx.x) * 2 * Cout;
+      for (int jj = tid; jj < C2n; jj += 256) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        for (int gg = 0; gg < Gn; ++gg) {
+          const float* row = Al + (long)gg * 4 * C2n;
+          t0 += row[jj]; t1 += row[C2n + jj]; t2 += row[2 * C2n + jj]; t3 += row[3 * C2n + jj];
+        }
+        if (s.additive) { prow[jj] = t0; prow[Cout + jj] = 3.f * t1; }
+        else {
+          prow[2 * jj] = t0; prow[2 * jj + 1] = t2;
+          prow[Cout + 2 * jj] = 3.f * t1; prow[Cout + 2 * jj + 1] = 3.f * t3;
+        }
+      }
+    }
+    if (MULTI && k > k_last) __syncthreads();   // the next step's staging overwrites what the epilogue read
   }
-  stamp(10);
+  }   // steps of the level
+#undef FBS
 }
 
 static int fb_ilog2_exact(int v) {
@@ -514,16 +801,16 @@ static bool fb_pick(const nfk_step2d& s, FBArgs* a) {
          (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4);
 }
 
-template <int MT32, int NTD, int K3M, int MO = 4>
+template <int MT32, int NTD, int K3M, int MO = 4, bool LV = false, bool MULTI = false>
 static int fb_launch_t(const FBArgs& a, const FBGeom& g, int grid, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusedb_step_bwd_kernel<MT32, NTD, K3M, MO>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusedb_step_bwd_kernel<MT32, NTD, K3M, MO, LV, MULTI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
       return NFK_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((fusedb_step_bwd_kernel<MT32, NTD, K3M, MO>), dim3(grid), dim3(256), g.total, st, a);
+  hipLaunchKernelGGL((fusedb_step_bwd_kernel<MT32, NTD, K3M, MO, LV, MULTI>), dim3(grid), dim3(256), g.total, st, a);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
@@ -573,6 +860,93 @@ int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
   else if (g.MT32 == 2 && g.NTD == 2 && g.K3M == 28) rc = fb_launch_t<2, 2, 28>(a, g, grid, st);
   prof_scope_end(cls, st);
   return rc;
+}
+
+
+// ------------------------------------------------------------------------------------------ level mode
+// tile choice of a level: as fusedb_launch (16- / 32-pixel tiles for 4x4 images on a small grid), the same for every
+// launch of the level -- the number of workgroups is the number of partial slabs / rows each step leaves
+static bool fb_level_pick(const nfk_step2d& s, FBArgs* a, FBGeom* gp, int* mo, int* grid) {
+  if (!fb_pick(s, a) || s.B > 256) return false;
+  FBGeom g = fb_geom_lv(s, a->R, a->TS, a->halo);
+  int npx = 64, gr = a->TS == 1 ? s.B * (s.H / a->R) : (s.B + a->TS - 1) / a->TS;
+  const int HW = s.H * s.W;
+  if (g_small_tiles && HW == 16 && a->halo == 0 && gr < 64 && g.NTD == 2 && g.K3M == 28) {
+    FBArgs h = *a;
+    const int np = gr < 32 ? 16 : 32;
+    h.TS = np / HW;
+    h.lrw = fb_ilog2_exact(h.R * s.W);
+    h.lhw = fb_ilog2_exact(h.R * s.W);
+    const FBGeom gh = fb_geom_lv(s, h.R, h.TS, h.halo);
+    if (gh.MT32 == 1 && (size_t)4 * np * gh.NTD * 16 * 4 <= (size_t)32 * 1024) {
+      *a = h; g = gh; npx = np; gr = (s.B + h.TS - 1) / h.TS;
+    }
+  }
+  const int C = s.C, C2 = C - C / 2;
+  if (g.total > 160 * 1024 - 512 || gr > 256 || gr < 1) return false;
+  if (fb_epi_floats(C, npx) * 4 > (size_t)g.MT32 * 32 * g.X3S) return false;    // the epilogue's scratch: the im2col region
+  if (npx * C > 12 * 256 || C * C > 9 * 256 || C2 < 1 || C2 > 256) return false;   // its register slots
+  if ((npx + 256 / C2 - 1) / (256 / C2) > 8) return false;                        // pixels per thread of the coupling backward
+  *gp = g; *mo = npx / 16; *grid = gr;
+  return true;
+}
+int fusedb_level_ok(const nfk_step2d& s) {
+  FBArgs a{};
+  FBGeom g;
+  int mo, grid;
+  if (!fb_level_pick(s, &a, &g, &mo, &grid)) return 0;
+  return a.halo == 0 ? 2 : 1;
+}
+int fusedb_level_grid(const nfk_step2d& s) {
+  FBArgs a{};
+  FBGeom g;
+  int mo, grid;
+  return fb_level_pick(s, &a, &g, &mo, &grid) ? grid : 0;
+}
+template <bool MULTI>
+static int fb_level_dispatch(const FBArgs& a, const FBGeom& g, int mo, int grid, hipStream_t st) {
+  if (mo == 1 && g.MT32 == 1 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<1, 2, 28, 1, true, MULTI>(a, g, grid, st);
+  if (mo == 2 && g.MT32 == 1 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<1, 2, 28, 2, true, MULTI>(a, g, grid, st);
+  if (mo != 4) return NFK_ERR_ARG;
+  if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) return fb_launch_t<2, 1, 8, 4, true, MULTI>(a, g, grid, st);
+  if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) return fb_launch_t<2, 1, 16, 4, true, MULTI>(a, g, grid, st);
+  if (g.MT32 == 2 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<2, 2, 28, 4, true, MULTI>(a, g, grid, st);
+  if (MULTI) return NFK_ERR_ARG;   // tiles with halo rows: one launch per step
+  if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) return fb_launch_t<3, 1, 8, 4, true, false>(a, g, grid, st);
+  if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) return fb_launch_t<3, 1, 4, 4, true, false>(a, g, grid, st);
+  return NFK_ERR_ARG;
+}
+int fusedb_level_launch(const FusedLevelCall& c, hipStream_t st, int* grid_used) {
+  FBArgs a{};
+  FBGeom g;
+  int mo, grid;
+  const nfk_step2d& s = c.first;
+  if (!fb_level_pick(s, &a, &g, &mo, &grid)) return NFK_ERR_ARG;
+  a.c.s = s;
+  a.lv = c.lv;
+  a.gz[0] = c.gz[0]; a.gz[1] = c.gz[1]; a.tailpart = c.tailpart;
+  a.ga = c.ga; a.ga_stride = c.ga_stride; a.o_ga2 = c.o_ga2; a.o_ga1 = c.o_ga1; a.o_x3 = c.o_x3;
+  if (grid_used) *grid_used = grid;
+  const double M = (double)s.B * s.H * s.W;
+  const int cls = NFK_PROF_FUSED_BWD + (M >= 8192 ? 0 : (M >= 2048 ? 1 : 2));
+  const double fl = 2.0 * M * (512.0 * 9 * s.Cout + 512.0 * 512 + 9.0 * 512 * (s.C / 2));
+  const double by = M * (4.0 * s.Cout + 4.0 * (s.C / 2) + 2 * 512 * 2.0 + 2 * 64.0) + 2.0 * 512 * (9.0 * s.Cout + 512 + 9.0 * (s.C / 2));
+  const int nwalk = c.lv.k_hi - c.lv.k_lo + 1;
+  if (c.lv.multi && a.halo == 0 && nwalk > 1) {
+    a.k_hi = c.lv.k_hi; a.k_lo = c.lv.k_lo;
+    prof_scope_begin(cls, nwalk * fl, nwalk * by, st);
+    const int rc = fb_level_dispatch<true>(a, g, mo, grid, st);
+    prof_scope_end(cls, st);
+    return rc;
+  }
+  for (int k = c.lv.k_hi; k >= c.lv.k_lo; --k) {
+    a.k_hi = a.k_lo = k;
+    prof_scope_begin(cls, fl, by, st);
+    const int rc = fb_level_dispatch<false>(a, g, mo, grid, st);
+    prof_scope_end(cls, st);
+    if (rc != NFK_OK) return rc;
+  }
+  return NFK_OK;
 }
 
 }  // namespace nfk

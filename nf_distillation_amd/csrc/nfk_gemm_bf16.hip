@@ -1066,6 +1066,118 @@ int wgrad_tail_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, in
   return NFK_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Level mode (nfk_level2d_bwd): the weight-gradient GEMMs and ActNorm sums of ALL steps of a level in ONE launch -- with
+// 3 K GEMMs side by side a split covers a quarter of the pixels or more (64+ chunks at CIFAR level 1) instead of a
+// sixteenth (16 chunks, each most of a memory round trip behind one chunk of prefetch), and writes 4 slabs instead of 16
+// -- and every reduction into the parameter gradients in ONE more.  Per-step operands are base + k * stride.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
+  const int ks = (int)blockIdx.x / a.per_step, k = a.k_lo + ks;
+  int b = (int)blockIdx.x - ks * a.per_step;
+  const float* gablk = a.ga + (long)k * a.ga_stride;
+  const __bf16* h1 = reinterpret_cast<const __bf16*>(a.h1) + (long)k * a.h_stride;
+  const __bf16* h2 = reinterpret_cast<const __bf16*>(a.h2) + (long)k * a.h_stride;
+  float* ws = a.wslab + (long)k * a.wslab_stride;
+  if (b < a.nparts) {
+    ActnormSumArgs an{};
+    an.ga2 = gablk + a.o_ga2; an.h2 = h2; an.ga1 = gablk + a.o_ga1; an.h1 = h1;
+    an.es2 = a.steps[k].es2; an.es1 = a.steps[k].es1; an.col2 = ws + a.o_col2; an.col1 = ws + a.o_col1;
+    an.M = a.M; an.hid = a.hid; an.nparts = a.nparts;
+    actnorm_sum_body(an, b);
+    return;
+  }
+  b -= a.nparts;
+  WgradArgs w{};
+  w.B = a.B; w.H = a.H; w.W = a.W; w.M = a.M; w.taps = 1; w.pbf16 = 1; w.qbf16 = 1;
+  if (b < a.nb2 * a.S) {          // block.2: [hid x M] [M x hid]
+    w.P = gablk + a.o_ga2; w.ldp = a.hid; w.NI = a.hid;
+    w.Q = reinterpret_cast<const float*>(h1); w.ldq = a.hid; w.Cq = a.hid; w.J = a.hid;
+    w.out = ws + a.o_s2; w.slab_stride = (long)a.hid * a.hid;
+    wgrad_bf16_body<4, 4, 2, 2, true>(w, b % a.nb2, a.S, b / a.nb2);
+    return;
+  }
+  b -= a.nb2 * a.S;
+  if (b < a.nb3 * a.S) {          // block.4 through dgrad3's im2col rows: [K3p x M] [M x hid]
+    w.P = gablk + a.o_x3; w.ldp = a.K3p; w.NI = a.K3p;
+    w.Q = reinterpret_cast<const float*>(h2); w.ldq = a.hid; w.Cq = a.hid; w.J = a.hid;
+    w.out = ws; w.slab_stride = (long)a.K3p * a.hid;
+    wgrad_bf16_body<4, 4, 2, 2, true>(w, b % a.nb3, a.S, b / a.nb3);
+    return;
+  }
+  b -= a.nb3 * a.S;
+  {                               // block.0 on the forward's im2col rows: [hid x M] [M x K1p]
+    w.P = gablk + a.o_ga1; w.ldp = a.hid; w.NI = a.hid;
+    w.Q = reinterpret_cast<const float*>(a.masks + (long)k * a.mask_stride + a.o_x1); w.ldq = a.K1p; w.Cq = a.K1p; w.J = a.K1p;
+    w.out = ws + a.o_s1; w.slab_stride = (long)a.hid * a.K1p;
+    wgrad_bf16_body<4, 4, 2, 2, true>(w, b % a.nb1, a.S, b / a.nb1);
+  }
+}
+
+__global__ void __launch_bounds__(256) level_tail_kernel(LevelWgradArgs a, StepTailArgs f, int per_tail) {
+  const int ks = (int)blockIdx.x / per_tail, k = a.k_lo + ks, blk = (int)blockIdx.x - ks * per_tail;
+  float* ws = a.wslab + (long)k * a.wslab_stride;
+  const nfk_level_grads g = a.grads[k];
+  SmallGradArgs sg{};
+  sg.col1 = ws + a.o_col1; sg.col2 = ws + a.o_col2; sg.mb1 = sg.mb2 = a.nparts; sg.n1 = sg.n2 = a.hid;
+  sg.tail = a.tailpart + (long)k * 256 * 2 * a.Cout; sg.B = (k == a.k_hi) ? a.rows_top : a.rows; sg.n3 = a.Cout;
+  sg.g_l1 = g.g_l1; sg.g_b1 = g.g_b1; sg.g_l2 = g.g_l2; sg.g_b2 = g.g_b2; sg.g_bias3 = g.g_bias3; sg.g_l3 = g.g_l3;
+  f.slabs[0] = ws; f.gradW[0] = g.g_w3;
+  f.slabs[1] = ws + a.o_s2; f.gradW[1] = g.g_w2;
+  f.slabs[2] = ws + a.o_s1; f.gradW[2] = g.g_w1;
+  step_tail_body(sg, f, blk);
+}
+
+int level_wgrad_tiles(int hid, int K3p, int K1p) {
+  return ceil_div(hid, 128) * ceil_div(hid, 128) + ceil_div(K3p, 128) * ceil_div(hid, 128) + ceil_div(hid, 128) * ceil_div(K1p, 128);
+}
+// splits per GEMM for a walk of `nwalk` steps: enough workgroups for the chip (two per CU fit), never fewer than 4 chunks each
+int level_wgrad_splits(int M, int hid, int K3p, int K1p, int nwalk) {
+  const int tiles = level_wgrad_tiles(hid, K3p, K1p) * (nwalk > 0 ? nwalk : 1), nchunks = ceil_div(M, WPX);
+  int S = ceil_div(640, tiles);
+  if (S > nchunks / 4) S = nchunks / 4;
+  if (S > NFK_LEVEL_MAX_SPLITS) S = NFK_LEVEL_MAX_SPLITS;
+  return S < 1 ? 1 : S;
+}
+
+int level_wgrad_launch(LevelWgradArgs a, hipStream_t st, hipStream_t st_tail) {
+  const int nwalk = a.k_hi - a.k_lo + 1;
+  if (nwalk < 1 || a.hid != 512 || ((a.K3p | a.K1p | a.hid) & 7) || a.M <= 0) return NFK_ERR_ARG;
+  if ((long)a.M * a.hid * 4 >= 0x7fffffffL) return NFK_ERR_ARG;
+  a.nb2 = ceil_div(a.hid, 128) * ceil_div(a.hid, 128);
+  a.nb3 = ceil_div(a.K3p, 128) * ceil_div(a.hid, 128);
+  a.nb1 = ceil_div(a.hid, 128) * ceil_div(a.K1p, 128);
+  a.nparts = actnorm_sum_parts(a.M);
+  a.per_step = a.nparts + (a.nb2 + a.nb3 + a.nb1) * a.S;
+  constexpr size_t ldsWide = 2 * WPX * (wg_stride(128) + wg_stride(128));
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(level_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  const int cls = NFK_PROF_TRIPLE_WGRAD + (a.M >= 8192 ? 0 : (a.M >= 2048 ? 1 : 2));
+  const double nj = (double)a.hid * (9.0 * a.Cout + a.hid + 9.0 * a.Ch);
+  prof_scope_begin(cls, nwalk * 2.0 * a.M * nj,
+                   nwalk * (a.M * (4.0 * a.hid + 2.0 * a.hid + 2.0 * a.K3p + 2.0 * a.K1p + 2.0 * a.hid) +
+                            4.0 * a.S * ((double)a.hid * a.hid + (double)a.K3p * a.hid + (double)a.hid * a.K1p)), st);
+  hipLaunchKernelGGL(level_wgrad_kernel, dim3(nwalk * a.per_step), dim3(256), ldsWide, st, a);
+  prof_scope_end(cls, st);
+  NFK_LAUNCH_CHECK();
+  // the reductions: per step as step_tail_body lays them out
+  SmallGradArgs sg{};
+  sg.n1 = sg.n2 = a.hid; sg.n3 = a.Cout;
+  StepTailArgs f{};
+  const int Co[3] = {a.Cout, a.hid, a.hid}, Ci[3] = {a.hid, a.hid, a.Ch}, tp[3] = {9, 1, 9}, md[3] = {1, 0, 0}, lj[3] = {a.hid, 0, a.K1p};
+  const long strd[3] = {(long)a.K3p * a.hid, (long)a.hid * a.hid, (long)a.hid * a.K1p};
+  for (int q = 0; q < 3; ++q) {
+    f.stride[q] = strd[q]; f.S[q] = a.S; f.Cout[q] = Co[q]; f.Cin[q] = Ci[q]; f.taps[q] = tp[q]; f.mode[q] = md[q]; f.ldj[q] = lj[q];
+  }
+  const int per_tail = tail_blocks(sg, f);
+  hipLaunchKernelGGL(level_tail_kernel, dim3(nwalk * per_tail), dim3(256), 0, st_tail, a, f, per_tail);
+  NFK_LAUNCH_CHECK();
+  return NFK_OK;
+}
+
 static int g_triple_skip = 0;
 void triple_wgrad_debug_skip(int mask) { g_triple_skip = mask; }
 

@@ -237,4 +237,30 @@ int wgrad_tail_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, in
                     const SmallGradArgs& a, StepTailArgs f, const ChanMixArgs& m, const CouplingBwdArgs* next, hipStream_t st,
                     double alg_nj);
 
+
+// ---- level mode (nfk_level2d_bwd) ----
+constexpr int NFK_LEVEL_MAX_SPLITS = 4;
+struct LevelWgradArgs {
+  const nfk_step2d* steps; const nfk_level_grads* grads;   // device arrays
+  int k_lo, k_hi;                                          // steps walked
+  int B, H, W, M, hid, Cout, Ch, K3p, K1p;
+  int S, nb3, nb2, nb1, nparts, per_step;                  // (nb*, nparts, per_step: filled by the launcher)
+  const float* ga; long ga_stride, o_ga2, o_ga1, o_x3;     // per-step gradient blocks (floats)
+  const void *h1, *h2; long h_stride;                      // bf16 elements
+  const unsigned char* masks; long mask_stride, o_x1;      // bytes
+  float* wslab; long wslab_stride, o_s2, o_s1, o_col2, o_col1;   // per step: slab3 | slab2 | slab1 | col2 | col1 (floats)
+  const float* tailpart; int rows_top, rows;               // [nsteps][256][2][Cout]; partial rows of step k_hi / the others
+};
+int level_wgrad_tiles(int hid, int K3p, int K1p);
+int level_wgrad_splits(int M, int hid, int K3p, int K1p, int nwalk);
+int level_wgrad_launch(LevelWgradArgs a, hipStream_t st, hipStream_t st_tail);
+// the dgrad chain + channel-mix backward + coupling backward of the step below, for steps k_hi .. k_lo of a level
+struct FusedLevelCall {
+  nfk_level_bwd lv;
+  nfk_step2d first;
+  float* gz[2]; float* tailpart; float* ga; long ga_stride, o_ga2, o_ga1, o_x3;
+};
+int fusedb_level_ok(const nfk_step2d& s);      // 1: level mode covers this geometry; 2: also as ONE launch for all steps
+int fusedb_level_grid(const nfk_step2d& s);    // workgroups of a step launch (what the one-launch form uses may differ: see fusedb_level_launch)
+int fusedb_level_launch(const FusedLevelCall& c, hipStream_t st, int* grid_used);
 }  // namespace nfk

@@ -66,6 +66,13 @@ class FlowEngine:
         # all FlowSteps of a level in ONE launch where the pixel tiles are whole images (nfk_run2d_fwd_fused; bit-identical
         # to the per-step launches without hidden split).  "inference": only for passes that keep nothing (a frozen teacher)
         self.fused_runs = True
+        # bf16 fused backward per LEVEL (nfk_level2d_bwd): one launch per step (dgrad chain + channel mix + the coupling
+        # backward of the step below) -- or ONE for all steps of a level whose tiles are whole images (`level_multi`) --, then
+        # one launch with the level's 3 K weight-gradient GEMMs and one with all reductions.  False: the per-step calls
+        # (nfk_step2d_bwd_chain), which the level form is tested against
+        self.level_backward = True
+        self.level_multi = True
+        self.level_wgrad_aux = False     # the two per-level launches on the auxiliary stream (`aux`), joined once per backward
         self.bwd_mode = capi.BWD_DEFAULT   # nfk_step2d_grads.bwd_mode: how the bf16 backward of a coupling net is launched
         self.defer_fused_wgrad = False   # bf16 fused backward: weight-gradient launches as a chain of their own on `aux`
         self.aux = None        # nfk_aux handle (training.enable_concurrency): auxiliary stream of the weight-gradient GEMMs
@@ -300,8 +307,29 @@ class FlowEngine:
                 else:
                     i += 1
 
+        # levels: maximal runs of FlowSteps of one geometry (the unit of nfk_level2d_bwd), keyed by their first layer index
+        levels = {}
+        if self.bf16 and not self.is_1d:
+            i = 0
+            while i < len(recs):
+                r = recs[i]
+                if r.kind != "step":
+                    i += 1
+                    continue
+                j = i
+                while (j < len(recs) and recs[j].kind == "step" and
+                       (recs[j].C, recs[j].H, recs[j].W, recs[j].hid, recs[j].Cout, recs[j].additive) ==
+                       (r.C, r.H, r.W, r.hid, r.Cout, r.additive)):
+                    j += 1
+                host = (Step2d * (j - i))(*[q.cs for q in recs[i:j]])
+                ok = bool(r.cs.wg1) and all(lib.nfk_step2d_fused_bwd_ok(C.byref(q.cs)) for q in recs[i:j])
+                levels[i] = {"n": j - i, "host": host, "bwd_ok": ok and bool(lib.nfk_level_bwd_ok(C.byref(r.cs))),
+                             "dev": (runs[i]["dev"] if (i in runs and runs[i]["n"] == j - i)
+                                     else capi.struct_array_to_device([q.cs for q in recs[i:j]], device))}
+                i = j
+
         self.state = {
-            "runs": runs,
+            "runs": runs, "levels": levels,
             "B": B, "recs": recs, "prep_buf": prep_buf, "pack_buf": pack_buf, "keep": keep,
             "prep_dev": capi.struct_array_to_device(prep_descs, device), "n_prep": len(prep_descs),
             "prep_host": prep_descs,
@@ -709,6 +737,7 @@ class _EncodeFn(torch.autograd.Function):
         scratch = _Scratch(st, dev)
         cur, cur_ld = None, None  # NHWC tensor of the running activation
         run, keep_alive = None, []
+        lv_saved = {}   # {index of a level's last FlowStep: its strided arenas}: the backward of a whole level (nfk_level2d_bwd)
         skip_until = 0
         # log-det partials of the fused launches (a level's steps, the fused Split2d) are summed onto `ld` in ONE launch where
         # the running value is next needed -- normally at the end of the pass: same arithmetic in the same order as one
@@ -765,6 +794,10 @@ class _EncodeFn(torch.autograd.Function):
                 fr.keep = sum(1 << k for k in kept)
                 check(lib.nfk_run2d_fwd_fused(C.byref(fr), C.byref(r.cs), s), "nfk_run2d_fwd_fused")
                 pending.append((ldbuf, n, tiles))
+                if need and mk_all is not None:   # what nfk_level2d_bwd addresses as base + k * stride
+                    lv_saved[r.idx + n - 1] = {"first": r.idx, "n": n, "x0": cur, "zc": zc, "hc": hc, "zo_all": zo_all,
+                                               "zs_all": zs_all, "h_all": h_all, "hs_all": hs_all, "mk_all": mk_all,
+                                               "mbytes": mbytes, "mh": M_ * r.hid}
                 slot = 0
                 for k in range(n):
                     out = None
@@ -814,11 +847,37 @@ class _EncodeFn(torch.autograd.Function):
                             break
                         n_run += 1
                     run = {"buf": torch.empty(n_run * B * tiles, device=dev, dtype=torch.float32), "k": 0, "n": n_run,
-                           "tiles": tiles}
+                           "tiles": tiles, "lv": None}
+                    lvi = st["levels"].get(r.idx)
+                    if need and r.cs.wg1 and lvi is not None and lvi["n"] == n_run and lvi["bwd_ok"]:
+                        # everything the steps of this level keep, in arenas addressed as base + k * stride (the layout of a
+                        # level that runs as one launch): what the backward of the whole level reads (nfk_level2d_bwd)
+                        Ml = B * r.H * r.W
+                        zc_, hc_ = _a4(Ml * r.C), _a4(Ml * r.Cout)
+                        mb_ = lib.nfk_step2d_mask_bytes(C.byref(r.cs))
+                        run["lv"] = {"first": r.idx, "n": n_run, "x0": cur, "zc": zc_, "hc": hc_, "mbytes": mb_, "mh": Ml * r.hid,
+                                     "zo_all": torch.empty(n_run * zc_, device=dev, dtype=torch.float32),
+                                     "zs_all": torch.empty(n_run * zc_, device=dev, dtype=torch.float32),
+                                     "h_all": torch.empty(2 * n_run * Ml * r.hid, device=dev, dtype=torch.bfloat16),
+                                     "hs_all": torch.empty(n_run * hc_, device=dev, dtype=torch.float32),
+                                     "mk_all": torch.empty(n_run * mb_, device=dev, dtype=torch.uint8)}
                 M_ = B * r.H * r.W
-                out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
+                lvr = run["lv"]
+                if lvr is not None:
+                    k_ = run["k"]
+                    out = lvr["zo_all"][k_ * lvr["zc"]: k_ * lvr["zc"] + M_ * r.C].view(B, r.H, r.W, r.C)
+                else:
+                    out = torch.empty((B, r.H, r.W, r.C), device=dev, dtype=torch.float32)
                 zb = h1 = h2 = hs = masks = None
-                if need:
+                if need and lvr is not None:
+                    k_, n_ = run["k"], run["n"]
+                    zb = lvr["zs_all"][k_ * lvr["zc"]: k_ * lvr["zc"] + M_ * r.C]
+                    h1 = lvr["h_all"][k_ * lvr["mh"]: (k_ + 1) * lvr["mh"]]
+                    h2 = lvr["h_all"][(n_ + k_) * lvr["mh"]: (n_ + k_ + 1) * lvr["mh"]]
+                    hs = lvr["hs_all"][k_ * lvr["hc"]: k_ * lvr["hc"] + M_ * r.Cout]
+                    masks = lvr["mk_all"][k_ * lvr["mbytes"]: (k_ + 1) * lvr["mbytes"]]
+                    saved.append((cur, zb, h1, h2, hs, None, masks))
+                elif need:
                     # ReLU masks of h1 / h2 (one bit per element) for the fused step backward, behind the other saves
                     nmask = _a4((lib.nfk_step2d_mask_bytes(C.byref(r.cs)) + 3) // 4) if r.cs.wg1 else 0
                     arena = torch.empty(_a4(M_ * r.C) + 2 * _a4(M_ * r.hid) + _a4(M_ * r.Cout) + nmask, device=dev,
@@ -850,6 +909,8 @@ class _EncodeFn(torch.autograd.Function):
                 run["k"] += 1
                 if run["k"] == run["n"]:
                     pending.append((run["buf"], run["n"], tiles))
+                    if run["lv"] is not None:
+                        lv_saved[r.idx] = run["lv"]
                     run = None
             elif r.kind == "step":
                 if cur is None:
@@ -903,6 +964,7 @@ class _EncodeFn(torch.autograd.Function):
                 eng.layer_hooks[r.idx]()
         ld = flush_ld(ld)
         ctx.saved = saved
+        ctx.levels = lv_saved
         ctx.x_contig = x.is_contiguous()
         return tuple(outs) + (ld,)
 
@@ -959,14 +1021,19 @@ class _EncodeFn(torch.autograd.Function):
         scratch = _Scratch(st, dev)
         # per-step partial (gWf, gcf) arena for nfk_prep_bwd
         part_off, total = {}, 0
+        levels_ok = (eng.level_backward and eng.bf16 and eng.fused and eng.bwd_mode in (capi.BWD_DEFAULT, capi.BWD_FUSED)
+                     and bool(getattr(ctx, "levels", None)))
         for r in recs:
             if r.kind == "step":
                 nb = lib.nfk_chanmix_blocks(B * r.H * r.W, r.C)
                 part_off[r.idx] = (total, nb)
+                if levels_ok:
+                    nb = max(nb, lib.nfk_level_bwd_parts(C.byref(r.cs)))
                 total += _a4(nb * (r.C * r.C + r.C))
         parts = st.get("parts")
         if parts is None or parts.numel() < max(total, 4):
             parts = st["parts"] = torch.empty(max(total, 4), device=dev, dtype=torch.float32)
+        nparts_used = {}   # {layer index: partial slabs its backward left in `parts`} where that is not part_off's count
 
         # With an auxiliary stream (training.enable_concurrency) and no per-layer gradient hook, the weight-gradient
         # GEMMs of ALL steps form one chain on that stream, fed by per-step gradient buffers, and are joined once at
@@ -1003,13 +1070,83 @@ class _EncodeFn(torch.autograd.Function):
                 ext_of[i] = _nhwc(go_i.to(torch.float32)) if go_i is not None else None
             return ext_of[i]
 
+        def level_backward(i, lvl, g):
+            """order[i] is the LAST FlowStep of a level whose forward kept its tensors in strided arenas: the whole level
+            through nfk_level2d_bwd (cut where a step's output carries an external gradient: such a step starts a new
+            walk).  Returns the gradient wrt the level's input."""
+            n, first = lvl["n"], lvl["first"]
+            info = st["levels"][first]
+            r0 = recs[first]
+            M_ = B * r0.H * r0.W
+            npart = lib.nfk_level_bwd_parts(C.byref(r0.cs))
+            # per-step gradient pointers (persistent buffers: uploaded once per set of pointers)
+            lg = []
+            for q in recs[first:first + n]:
+                blk = q.mod.block
+                d = capi.LevelGrads()
+                d.g_w1, d.g_b1, d.g_l1 = ptr(blk[0].conv.weight.grad), ptr(blk[0].actnorm.bias.grad), ptr(blk[0].actnorm.logs.grad)
+                d.g_w2, d.g_b2, d.g_l2 = ptr(blk[2].conv.weight.grad), ptr(blk[2].actnorm.bias.grad), ptr(blk[2].actnorm.logs.grad)
+                d.g_w3, d.g_bias3, d.g_l3 = ptr(blk[4].conv.weight.grad), ptr(blk[4].conv.bias.grad), ptr(blk[4].logs.grad)
+                d.mix_part = parts.data_ptr() + 4 * part_off[q.idx][0]
+                lg.append(d)
+                nparts_used[q.idx] = npart
+            sig = tuple((d.g_w1, d.g_b1, d.g_l1, d.g_w2, d.g_b2, d.g_l2, d.g_w3, d.g_bias3, d.g_l3, d.mix_part) for d in lg)
+            cache = st.setdefault("level_grads", {})
+            if first not in cache or cache[first][0] != sig:
+                cache[first] = (sig, capi.struct_array_to_device(lg, dev))
+            wsz = lib.nfk_level_bwd_ws_floats(C.byref(r0.cs), n)
+            wsc = st.setdefault("level_ws", {})
+            if first not in wsc or wsc[first].numel() < wsz:
+                wsc[first] = torch.empty(wsz, device=dev, dtype=torch.float32)
+            lv = capi.LevelBwd()
+            lv.steps, lv.grads, lv.nsteps = info["dev"].data_ptr(), cache[first][1].data_ptr(), n
+            lv.x0, lv.ldx0 = lvl["x0"].data_ptr(), r0.C
+            lv.zout, lv.zout_stride = lvl["zo_all"].data_ptr(), lvl["zc"]
+            lv.zsave, lv.zsave_stride = lvl["zs_all"].data_ptr(), lvl["zc"]
+            lv.hsave, lv.hsave_stride = lvl["hs_all"].data_ptr(), lvl["hc"]
+            lv.h1save, lv.h2save, lv.h_stride = lvl["h_all"].data_ptr(), lvl["h_all"].data_ptr() + 2 * n * lvl["mh"], lvl["mh"]
+            lv.masks, lv.mask_stride = lvl["mk_all"].data_ptr(), lvl["mbytes"]
+            lv.g_ld, lv.ws = ptr(g_ld), wsc[first].data_ptr()
+            lv.multi = 1 if eng.level_multi else 0
+            lv.aux = eng.aux if (eng.level_wgrad_aux and eng.grad_hook is None) else None
+            k_hi = n - 1
+            while k_hi >= 0:
+                ext = _ext(i + (n - 1 - k_hi))
+                k_lo = k_hi
+                while k_lo > 0 and _ext(i + (n - 1 - (k_lo - 1))) is None:
+                    k_lo -= 1
+                g_main, g_e = (g, ext) if g is not None else (ext, None)
+                gx = torch.empty((B, r0.H, r0.W, r0.C), device=dev, dtype=torch.float32)
+                lv.g_out, lv.g_ext, lv.g_x = ptr(g_main), ptr(g_e), ptr(gx)
+                lv.k_lo, lv.k_hi = k_lo, k_hi
+                check(lib.nfk_level2d_bwd(C.byref(lv), info["host"], s), "nfk_level2d_bwd")
+                if lv.aux:
+                    aux_used.append(True)
+                keep_alive.append((g_main, g_e))
+                g = gx
+                k_hi = k_lo - 1
+            if eng.grad_hook is not None:
+                eng.grad_hook(first)   # every layer of the level at once: its gradients are final behind the level's last launch
+            return g
+
+        aux_used, keep_alive = [], []
         g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
         rows_in, n_step = 0, 0   # partial rows the previous call left for this step (0: none); steps processed
+        skip_to = 0
         for i, (r, sv, go) in enumerate(order):
+            if i < skip_to:
+                continue   # part of a level that one call has walked
             ext = _ext(i)
             if g is None and ext is None:
                 continue  # nothing flows into this layer's output
-            if r.kind == "step" and ws_pair is not None:
+            if r.kind == "step" and levels_ok and r.idx in ctx.levels and st["levels"][ctx.levels[r.idx]["first"]]["bwd_ok"]:
+                if pend is not None:   # what a per-step call before this level still owes
+                    check(lib.nfk_step2d_pending_flush(C.byref(pend), s), "nfk_step2d_pending_flush")
+                lvl = ctx.levels[r.idx]
+                g = level_backward(i, lvl, g)
+                skip_to = i + lvl["n"]
+                rows_in = 0
+            elif r.kind == "step" and ws_pair is not None:
                 x_in, zb, h1, h2, hs, _, masks = sv
                 blk = r.mod.block
                 gs = Step2dGrads()
@@ -1100,7 +1237,7 @@ class _EncodeFn(torch.autograd.Function):
 
         if pend is not None:
             check(lib.nfk_step2d_pending_flush(C.byref(pend), s), "nfk_step2d_pending_flush")
-        if deferred:
+        if deferred or aux_used:
             check(lib.nfk_aux_join(eng.aux, s), "nfk_aux_join")
         # parameter-side chain for all steps in one launch
         pg = []
@@ -1108,7 +1245,7 @@ class _EncodeFn(torch.autograd.Function):
             d = PrepGrad()
             if r.kind == "step":
                 off, nb = part_off[r.idx]
-                d.part, d.nparts = parts.data_ptr() + 4 * off, nb
+                d.part, d.nparts = parts.data_ptr() + 4 * off, nparts_used.get(r.idx, nb)
                 an = r.mod.actnorm
                 d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
                 if r.mod.flow_permutation_type == "invconv":
@@ -1119,12 +1256,12 @@ class _EncodeFn(torch.autograd.Function):
                         d.g_weight = ptr(ic.weight.grad)
             if r.kind in ("step", "split"):
                 pg.append(d)
-        sig = tuple((d.part, d.g_an_bias, d.g_lower, d.g_weight) for d in pg)
+        sig = tuple((d.part, d.nparts, d.g_an_bias, d.g_lower, d.g_weight) for d in pg)
         if st["grad_sig"] != sig:
             st["grad_dev"], st["grad_sig"] = capi.struct_array_to_device(pg, dev), sig
         check(lib.nfk_prep_bwd(ptr(st["prep_dev"]), ptr(st["grad_dev"]), st["n_prep"], ptr(g_ld), B, st["any_dense"], s),
               "nfk_prep_bwd")
-        ctx.keep = (parts,)
+        ctx.keep = (parts, keep_alive)
         gx = g if ctx.needs_input_grad[1] else None
         if gx is not None and gx.dim() == 4 and recs[0].kind != "squeeze":
             gx = gx.permute(0, 3, 1, 2)
