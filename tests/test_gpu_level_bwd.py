@@ -48,7 +48,7 @@ def _grads(cfg, B, seed, mode, hints):
 
 
 def _compare(a, b, what, x_tol=1e-6):
-    worst = (0.0, None)
+    worst = (0.0, "")
     for k in b:
         scale = float(b[k].abs().max())
         if scale == 0.0:

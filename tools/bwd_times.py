@@ -10,6 +10,7 @@ from param_util import randomize_state_dict, shapes_of, synthetic_images
 from oracle_check import cifar_cfg
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+only = sys.argv[2] if len(sys.argv) > 2 else None   # run one form only (for rocprofv3): "steps", "level", "runs", "aux"
 m = nfa.create_glow_model(cifar_cfg(8))
 m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), 11))
 m = m.cuda().set_compute_dtype("bf16")
@@ -18,17 +19,21 @@ x, noise = synthetic_images(64, seed=3)
 x, noise = x.cuda(), noise.cuda()
 side = torch.cuda.Stream()
 aux = capi.lib().nfk_aux_create(side.cuda_stream)
-for name, lb, lm, ax in (("per-step chain", False, False, False), ("level, one launch per step", True, False, False),
-                         ("level, runs", True, True, False), ("level, runs, wgrad on aux", True, True, True)):
+for tag, name, lb, lm, ax in (("steps", "per-step chain", False, False, False), ("level", "level, one launch per step", True, False, False),
+                              ("runs", "level, runs", True, True, False), ("aux", "level, runs, wgrad on aux", True, True, True)):
+    if only and tag != only:
+        continue
     eng.level_backward, eng.level_multi = lb, lm
     eng.aux, eng.level_wgrad_aux = (aux if ax else None), ax
 
     def step():
-        for p in m.parameters():
-            if p.grad is not None:
-                p.grad.zero_()
+        if grads:
+            torch._foreach_zero_(grads)
         _, bpd, _ = m(x.clone(), None, noise=noise)
         bpd.mean().backward()
+    grads = []
+    step()
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
     for _ in range(3):
         step()
     g = torch.cuda.CUDAGraph()
