@@ -126,11 +126,19 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_fb[];
   const nfk_step2d& s = a.c.s;   // dimensions (the same for every step of a level); per-step POINTERS go through FBS
   const int k_first = LV ? a.k_hi : 0, k_last = LV ? (MULTI ? a.k_lo : a.k_hi) : 0;
+  // registers that live from one step of a run to the next: the ReLU mask words, e^logs values and dgrad3's first weight
+  // tiles of the NEXT step are requested before the current step's epilogue and travel under it
+  constexpr int W3R = (K3M >= 28) ? 1 : ((K3M >= 16) ? 2 : 4);   // register ring: tiles of 32 output channels held ahead
+                                                                  // (1: every fragment is reloaded in place right after its use)
+  bf16x8f w3[W3R][K3M];
+  u32x4f mk2[MT32];
+  unsigned mk1[MT32][4];
+  float ereg[4];
   for (int k = k_first; k >= k_last; --k) {
   // (a run of steps: thread index and dimensions pass through an empty asm once per step so that what derives from them
   //  is computed where it is used instead of being hoisted out of the step loop and kept live across it: nfk_fused2.hip)
   int tid_ = threadIdx.x, W_ = s.W, H_ = s.H, C_ = s.C, Cout_ = s.Cout, R_ = a.R, TS_ = a.TS;
-  if (MULTI) {
+  if (LV) {
     asm volatile("" : "+v"(tid_));
     asm volatile("" : "+s"(W_), "+s"(H_), "+s"(C_), "+s"(Cout_), "+s"(R_), "+s"(TS_));
   }
@@ -171,14 +179,40 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   // ------------------------------------------------------------------ 0. dgrad3's weights -> registers (in flight during 1.)
   const int swid = __builtin_amdgcn_readfirstlane(wid);
   const int voffL = lane * 16;
-  constexpr int W3R = (K3M >= 28) ? 1 : ((K3M >= 16) ? 2 : 4);   // register ring: tiles of 32 output channels held ahead
-                                                                  // (1: every fragment is reloaded in place right after its use)
-  bf16x8f w3[W3R][K3M];
   const __amdgpu_buffer_rsrc_t r3 = fb_rsrc(FBS(wg3), (unsigned)HID * g.K3p * 2);
-  auto load_w3 = [&](int j, bf16x8f (&f)[K3M]) {   // row tile (32 channels) swid*4 + j
+  auto load_w3r = [&](const __amdgpu_buffer_rsrc_t& r, int j, bf16x8f (&f)[K3M]) {   // row tile (32 channels) swid*4 + j
     const int soff = (swid * 4 + j) * K3M * 1024;
 #pragma unroll
-    for (int ks = 0; ks < K3M; ++ks) f[ks] = fb_ldw(r3, voffL, soff + ks * 1024);
+    for (int ks = 0; ks < K3M; ++ks) f[ks] = fb_ldw(r, voffL, soff + ks * 1024);
+  };
+  auto load_w3 = [&](int j, bf16x8f (&f)[K3M]) { load_w3r(r3, j, f); };
+  // ReLU mask words of this lane's pixel in every 32-pixel tile of the h-region (zero outside the image / the batch:
+  // the gradients there are the zero padding of dgrad1): mk2[mt] = the 4 words of the wave's channel tiles in dgrad3
+  // (tiles wid*4 .. wid*4+3), mk1[mt][i] = the word of tile i*4 + wid in dgrad2.  Requested first, used in the epilogues.
+  auto load_masks = [&](const unsigned char* mp) {
+    constexpr unsigned FB_OOB = 0x80000000u;
+    const long msz = (long)s.B * HW * (HID / 8);
+    const __amdgpu_buffer_rsrc_t rm1 = fb_rsrc(mp, (unsigned)msz), rm2 = fb_rsrc(mp + msz, (unsigned)msz);
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt) {
+      const int ph = mt * 32 + l32;
+      const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
+      const int rr = rem >> lw, xx = rem & (W - 1);
+      const int y = row0 + rr - halo, b = b0 + sm;
+      const bool ok = ph < g.P_h && (unsigned)y < (unsigned)H && b < s.B;
+      const int moff = ((b * HW + y * W + xx) * (HID / 8));
+      mk2[mt] = __builtin_amdgcn_raw_buffer_load_b128(rm2, ok ? moff + wid * 16 : (int)FB_OOB, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        mk1[mt][i] = __builtin_amdgcn_raw_buffer_load_b32(rm1, ok ? moff + (i * 4 + wid) * 4 : (int)FB_OOB, 0, 0);
+    }
+  };
+  // e^logs of the two ActNorm layers and dgrad3's first weight tiles of a step
+  auto load_es_w3 = [&](const float* es2p, const float* es1p, const void* wg3p) {
+    ereg[0] = es2p[tid]; ereg[1] = es2p[tid + 256]; ereg[2] = es1p[tid]; ereg[3] = es1p[tid + 256];
+    const __amdgpu_buffer_rsrc_t rk = fb_rsrc(wg3p, (unsigned)HID * g.K3p * 2);
+#pragma unroll
+    for (int j = 0; j < W3R; ++j) load_w3r(rk, j, w3[j]);
   };
 
   // rows of the LDS image -> rows of a global [M][512] bf16 array, for the tile's own 64 pixels; 16-byte pieces, a
@@ -197,28 +231,9 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   };
 
   // ------------------------------------------------------------------ 1. stage g_a3 (+2 halo rows), parameters, ReLU masks
-  // ReLU mask words of this lane's pixel in every 32-pixel tile of the h-region (zero outside the image / the batch:
-  // the gradients there are the zero padding of dgrad1): mk2[mt] = the 4 words of the wave's channel tiles in dgrad3
-  // (tiles wid*4 .. wid*4+3), mk1[mt][i] = the word of tile i*4 + wid in dgrad2.  Requested first, used in the epilogues.
-  u32x4f mk2[MT32];
-  unsigned mk1[MT32][4];
+  const bool fresh = !MULTI || k == k_first;   // (later steps of a run: requested before the epilogue of the step above)
+  if (fresh) load_masks(c_masks);
   {
-    constexpr unsigned FB_OOB = 0x80000000u;
-    const long msz = (long)s.B * HW * (HID / 8);
-    const __amdgpu_buffer_rsrc_t rm1 = fb_rsrc(c_masks, (unsigned)msz), rm2 = fb_rsrc(c_masks + msz, (unsigned)msz);
-#pragma unroll
-    for (int mt = 0; mt < MT32; ++mt) {
-      const int ph = mt * 32 + l32;
-      const int sm = (TS == 1) ? 0 : (ph >> lhw), rem = (TS == 1) ? ph : (ph & ((1 << lhw) - 1));
-      const int rr = rem >> lw, xx = rem & (W - 1);
-      const int y = row0 + rr - halo, b = b0 + sm;
-      const bool ok = ph < g.P_h && (unsigned)y < (unsigned)H && b < s.B;
-      const int moff = ((b * HW + y * W + xx) * (HID / 8));
-      mk2[mt] = __builtin_amdgcn_raw_buffer_load_b128(rm2, ok ? moff + wid * 16 : (int)FB_OOB, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        mk1[mt][i] = __builtin_amdgcn_raw_buffer_load_b32(rm1, ok ? moff + (i * 4 + wid) * 4 : (int)FB_OOB, 0, 0);
-    }
     constexpr int GMAX = 12;   // per-thread slots: TS*RZ*W*Cout <= 3072 (checked on the host)
     const int rowlen = W * Cout, per_s = g.RZ * rowlen, nx = TS * per_s;
     const int lo = (TS == 1) ? max(0, zh - row0) * rowlen : 0;                                     // elements inside the image
@@ -251,9 +266,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         }
       }
     }
-    const float e2a = FBS(es2)[tid], e2b = FBS(es2)[tid + 256], e1a = FBS(es1)[tid], e1b = FBS(es1)[tid + 256];
-#pragma unroll
-    for (int j = 0; j < W3R; ++j) load_w3(j, w3[j]);
+    if (fresh) load_es_w3(FBS(es2), FBS(es1), FBS(wg3));
     if (stage) {
 #pragma unroll
       for (int i = 0; i < GMAX; ++i) {
@@ -273,7 +286,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         }
       }
     }
-    Pe2[tid] = e2a; Pe2[tid + 256] = e2b; Pe1[tid] = e1a; Pe1[tid + 256] = e1b;
+    Pe2[tid] = ereg[0]; Pe2[tid + 256] = ereg[1]; Pe1[tid] = ereg[2]; Pe1[tid + 256] = ereg[3];
     if (tid < 16) reinterpret_cast<unsigned*>(smem_fb + g.oZero + (tid >> 2) * 256)[tid & 3] = 0u;
   }
   __syncthreads();
@@ -473,24 +486,6 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     for (int c = 0; c < D1; ++c)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) load_w1(c, c, tap);
-    if (LV) {
-      // level mode: the epilogue's operands -- the step's input rows on the tile (x_in: the other factor of the partial
-      // g_z x^T) and Wf -- are requested here too and parked in the dead im2col region behind the epilogue below
-      const float* xin = k == 0 ? a.lv.x0 : a.lv.zout + (long)(k - 1) * a.lv.zout_stride;
-      const int ldxi = k == 0 ? a.lv.ldx0 : C;
-      const int nzp = min(s.B - b0, TS) * R * W;   // valid pixels of the tile
-      const long m0 = (long)b0 * HW + (long)row0 * W;
-      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
-      const float* Wfp = FBS(Wf);
-#pragma unroll
-      for (int i = 0; i < EXMAX; ++i) {
-        const int e = min(tid + 256 * i, nzp * C - 1);
-        const int po = (int)__umulhi((unsigned)e, mC);
-        exreg[i] = xin[(m0 + po) * ldxi + (e - po * C)];
-      }
-#pragma unroll
-      for (int i = 0; i < EWMAX; ++i) ewreg[i] = Wfp[min(tid + 256 * i, C * C - 1)];
-    }
     __syncthreads();   // every wave is done reading g_a2: g_a1 takes its place in the image (same layout)
     stamp(6);
     char* imw[MT32];
@@ -518,25 +513,23 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   float* const Al = Wl + C * Cp4;                    // [256 / C2][4][C2] column sums of the coupling backward
   float* const GZl = reinterpret_cast<float*>(smem_fb + g.oGZ);   // [NPX][XS] dL/dz on the tile
   if (LV) {
-    const int nzp = min(s.B - b0, TS) * R * W;
-    const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+      // level mode: the epilogue's operands -- the step's input rows on the tile (x_in: the other factor of the partial
+      // g_z x^T) and Wf -- are requested here and travel under dgrad1
+      const float* xin = k == 0 ? a.lv.x0 : a.lv.zout + (long)(k - 1) * a.lv.zout_stride;
+      const int ldxi = k == 0 ? a.lv.ldx0 : C;
+      const int nzp = min(s.B - b0, TS) * R * W;   // valid pixels of the tile
+      const long m0 = (long)b0 * HW + (long)row0 * W;
+      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+      const float* Wfp = FBS(Wf);
 #pragma unroll
-    for (int i = 0; i < EXMAX; ++i) {
-      const int e = tid + 256 * i;
-      if (e < NPX * C) {
+      for (int i = 0; i < EXMAX; ++i) {
+        const int e = min(tid + 256 * i, nzp * C - 1);
         const int po = (int)__umulhi((unsigned)e, mC);
-        XIl[po * XS + (e - po * C)] = (e < nzp * C) ? exreg[i] : 0.f;
+        exreg[i] = xin[(m0 + po) * ldxi + (e - po * C)];
       }
-    }
 #pragma unroll
-    for (int i = 0; i < EWMAX; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < C * C) {
-        const int r = (int)__umulhi((unsigned)idx, mC);
-        Wl[r * Cp4 + (idx - r * C)] = ewreg[i];   // Wm[r][q]: in = r, out = q (chanmix_body, trans)
-      }
+      for (int i = 0; i < EWMAX; ++i) ewreg[i] = Wfp[min(tid + 256 * i, C * C - 1)];
     }
-  }
   save_rows(reinterpret_cast<__bf16*>(c_ga1));
   stamp(8);
 
@@ -622,20 +615,55 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     const int C2n = C - Ch, Gn = 256 / C2n, G4 = Cp4 / 4;
     const bool below = k > a.lv.k_lo;   // the coupling backward of step k - 1 rides along
     CStep* spn = (CStep*)(a.lv.steps + (below ? k - 1 : k));
+    if (MULTI) {
+      // a run: the next step's masks, e^logs and first dgrad3 tiles travel under this epilogue.  Unconditional -- the last
+      // step requests its own once more -- so that the carried registers are redefined HERE on every path (conditionally
+      // assigned, their old values would stay live through the whole body of the loop)
+      CStep* spq = (CStep*)(a.lv.steps + max(k - 1, k_last));
+      load_masks(reinterpret_cast<const unsigned char*>(a.lv.masks) + (long)max(k - 1, k_last) * a.lv.mask_stride);
+      load_es_w3(spq->es2, spq->es1, spq->wg3);
+    }
     const int jn = tid % C2n, gn = tid / C2n;
     const long mt0 = (long)b0 * HW + (long)row0 * W;   // first pixel of the tile (its pixels are contiguous in [M])
     const int nzp = min(s.B - b0, TS) * R * W;         // ... and how many of them exist
     // operands of the coupling backward below: (shift | scale) rows and z2 of step k - 1, requested before the mat-vec
     constexpr int CPF = 8;   // pixels per thread: NPX / Gn <= 7 (checked on the host)
-    float ch0[CPF], ch1[CPF], cz[CPF];
+    // (everything the coupling loop reads from global memory is requested HERE: inside the loop, behind its stores, every
+    //  load would wait for a full round trip -- the compiler must assume the stores alias it)
+    float ch0[CPF], ch1[CPF], cz[CPF], glv[CPF], e3a = 0.f, e3b = 0.f;
     if (below && gn < Gn) {
-      const float* hn = a.lv.hsave + (long)(k - 1) * a.lv.hsave_stride + mt0 * Cout;
-      const float* zn = a.lv.zsave + (long)(k - 1) * a.lv.zsave_stride + mt0 * C;
+      const float* __restrict__ hn = a.lv.hsave + (long)(k - 1) * a.lv.hsave_stride + mt0 * Cout;
+      const float* __restrict__ zn = a.lv.zsave + (long)(k - 1) * a.lv.zsave_stride + mt0 * C;
+      const float* __restrict__ es3n = spn->es3;
 #pragma unroll
       for (int e = 0; e < CPF; ++e) {
         const int pp = min(gn + e * Gn, nzp - 1);
-        if (s.additive) { ch0[e] = hn[pp * Cout + jn]; ch1[e] = 0.f; cz[e] = 0.f; }
-        else { ch0[e] = hn[pp * Cout + 2 * jn]; ch1[e] = hn[pp * Cout + 2 * jn + 1]; cz[e] = zn[pp * C + Ch + jn]; }
+        if (s.additive) { ch0[e] = hn[pp * Cout + jn]; ch1[e] = 0.f; cz[e] = 0.f; glv[e] = 0.f; }
+        else {
+          ch0[e] = hn[pp * Cout + 2 * jn]; ch1[e] = hn[pp * Cout + 2 * jn + 1]; cz[e] = zn[pp * C + Ch + jn];
+          glv[e] = a.lv.g_ld ? a.lv.g_ld[b0 + (pp >> lrw)] : 0.f;
+        }
+      }
+      if (s.additive) e3a = es3n[jn];
+      else { e3a = es3n[2 * jn]; e3b = es3n[2 * jn + 1]; }
+    }
+    {   // x_in and Wf, requested before dgrad1, into the scratch
+      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+#pragma unroll
+      for (int i = 0; i < EXMAX; ++i) {
+        const int e = tid + 256 * i;
+        if (e < NPX * C) {
+          const int po = (int)__umulhi((unsigned)e, mC);
+          XIl[po * XS + (e - po * C)] = (e < nzp * C) ? exreg[i] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < EWMAX; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < C * C) {
+          const int r = (int)__umulhi((unsigned)idx, mC);
+          Wl[r * Cp4 + (idx - r * C)] = ewreg[i];   // Wm[r][q]: in = r, out = q (chanmix_body, trans)
+        }
       }
     }
     // g_z1 = (dL/dz1 of the step's output) + dgrad1, the four waves' partial sums in the order the stand-alone kernel adds them
@@ -686,9 +714,8 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     if (below) {
       // -------------------------------------------------------------- 7. coupling backward of step k - 1 on the tile
       __syncthreads();   // g_x is complete; the partial sums above are done with GZl (overwritten below in a run)
-      float* gan = a.ga + (long)(k - 1) * a.ga_stride + mt0 * Cout;     // g_a3 of step k - 1 (the weight gradients read it too)
-      float* gzn = a.gz[(k - 1) & 1] + mt0 * C;
-      const float* es3n = spn->es3;
+      float* __restrict__ gan = a.ga + (long)(k - 1) * a.ga_stride + mt0 * Cout;   // g_a3 of step k - 1 (the weight gradients read it too)
+      float* __restrict__ gzn = a.gz[(k - 1) & 1] + mt0 * C;
       float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
       float gz2n[CPF];
       if (gn < Gn) {
@@ -702,16 +729,16 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
               const float g2 = GXl[pp * XS + Ch + jn];
               if (s.additive) {
                 gz2n[e] = g2;
-                v0 = g2 * es3n[jn];
+                v0 = g2 * e3a;
                 sb0 += v0; sl0 += g2 * ch0[e];
               } else {
-                const float gl = a.lv.g_ld ? a.lv.g_ld[b0 + pp / (R * W)] : 0.f;
+                const float gl = glv[e];
                 const float shf = ch0[e], sr = ch1[e];
                 const float sc = sigmoidf(sr + 2.f);
                 const float gshift = g2 * sc;
                 const float gsr = g2 * (cz[e] + shf) * sc * (1.f - sc) + gl * (1.f - sc);
                 gz2n[e] = gshift;
-                v0 = gshift * es3n[2 * jn]; v1 = gsr * es3n[2 * jn + 1];
+                v0 = gshift * e3a; v1 = gsr * e3b;
                 sb0 += v0; sl0 += gshift * shf; sb1 += v1; sl1 += gsr * sr;
               }
               if (s.additive) gan[pp * Cout + jn] = v0;

@@ -249,7 +249,13 @@ __device__ __forceinline__ void partial_rows_sum(const float* __restrict__ src, 
 // One launch for everything a FlowStep's backward still owes its parameters once the GEMMs are done: the three
 // split-slab reductions of the weight gradients (wgrad finalize: gradW[co][ci][tap] += sum_s slab[s][co][tap*Cin+ci])
 // and the small per-channel gradients above.  blockIdx.x ranges select the task.
-__device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const StepTailArgs& f, const int blk) {
+// (`ov`: level mode -- the three slab bases and gradient pointers of THIS step, the rest of `f` being the same for every step
+//  of the level: passed beside it, because a modified private copy of the argument struct would live in scratch memory)
+struct StepTailOverride { const float* slabs[3]; float* gradW[3]; };
+template <bool OV = false>
+__device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const StepTailArgs& f, const int blk,
+                                               const float* s0 = nullptr, const float* s1 = nullptr, const float* s2 = nullptr,
+                                               float* w0 = nullptr, float* w1 = nullptr, float* w2 = nullptr) {
   const int nsg = f.sg_blocks * 3;
   if (blk < nsg) {
     __shared__ float red[2][8][32];
@@ -278,8 +284,8 @@ __device__ __forceinline__ void step_tail_body(const SmallGradArgs& a, const Ste
   while (k < 2 && b >= f.blocks[k]) { b -= f.blocks[k]; ++k; }
   const int S = f.S[k], Cin = f.Cin[k], taps = f.taps[k], J = Cin * taps;
   const int total = f.Cout[k] * J;
-  const float* slabs = f.slabs[k];
-  float* gw = f.gradW[k];
+  const float* slabs = OV ? (k == 0 ? s0 : (k == 1 ? s1 : s2)) : f.slabs[k];
+  float* gw = OV ? (k == 0 ? w0 : (k == 1 ? w1 : w2)) : f.gradW[k];
   const int ldj = f.ldj[k] ? f.ldj[k] : J, mode = f.mode[k];
   for (int t = b * 256 + threadIdx.x; t < total; t += f.blocks[k] * 256) {
     const int r = t / taps, tap = t - r * taps;
