@@ -707,6 +707,7 @@ int nfk_level2d_bwd(const nfk_level_bwd* lv, const nfk_step2d* host_steps, void*
   FusedLevelCall fc{};
   fc.lv = *lv; fc.first = *s;
   fc.gz[0] = ws + L.gz0; fc.gz[1] = ws + L.gz1; fc.tailpart = ws + L.tailpart;
+  fc.stamps = g_bwd_stamps;
   fc.ga = ws + L.ga; fc.ga_stride = (long)L.ga_stride; fc.o_ga2 = (long)L.o_ga2; fc.o_ga1 = (long)L.o_ga1; fc.o_x3 = (long)L.o_x3;
   int grid = 0;
   NFK_TRY(fusedb_level_launch(fc, st, &grid));

@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   const int row0 = tile * R;
   const int zh = 2 * halo;
   auto stamp = [&](int i) {
-    if (!LV && a.c.stamps && tid == 0) a.c.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
+    if (a.c.stamps && tid == 0 && (!LV || k == k_last))   // level mode: the phases of the last step of the launch
+      a.c.stamps[(long)blockIdx.x * 16 + i] = __builtin_readcyclecounter();
   };
   stamp(0);
 
@@ -512,24 +513,28 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   float* const Wl = GXl + NPX * XS;                  // [C][Cp4]   Wf as [in][out]
   float* const Al = Wl + C * Cp4;                    // [256 / C2][4][C2] column sums of the coupling backward
   float* const GZl = reinterpret_cast<float*>(smem_fb + g.oGZ);   // [NPX][XS] dL/dz on the tile
-  if (LV) {
-      // level mode: the epilogue's operands -- the step's input rows on the tile (x_in: the other factor of the partial
-      // g_z x^T) and Wf -- are requested here and travel under dgrad1
-      const float* xin = k == 0 ? a.lv.x0 : a.lv.zout + (long)(k - 1) * a.lv.zout_stride;
-      const int ldxi = k == 0 ? a.lv.ldx0 : C;
-      const int nzp = min(s.B - b0, TS) * R * W;   // valid pixels of the tile
-      const long m0 = (long)b0 * HW + (long)row0 * W;
-      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
-      const float* Wfp = FBS(Wf);
+  // level mode: the epilogue's operands -- the step's input rows on the tile (x_in: the other factor of the partial
+  // g_z x^T) and Wf.  Requested before dgrad1 and travelling under it where the registers allow (21 more live values);
+  // the 96-pixel tiles of a level with halo rows are at the limit already (scratch traffic shares the vector-memory
+  // queue with the weight stream): there they are requested at the start of the epilogue
+  constexpr bool EARLY_PF = MT32 < 3;
+  auto prefetch_epi = [&]() {
+    const float* xin = k == 0 ? a.lv.x0 : a.lv.zout + (long)(k - 1) * a.lv.zout_stride;
+    const int ldxi = k == 0 ? a.lv.ldx0 : C;
+    const int nzq = min(s.B - b0, TS) * R * W;   // valid pixels of the tile
+    const long m0 = (long)b0 * HW + (long)row0 * W;
+    const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+    const float* Wfp = FBS(Wf);
 #pragma unroll
-      for (int i = 0; i < EXMAX; ++i) {
-        const int e = min(tid + 256 * i, nzp * C - 1);
-        const int po = (int)__umulhi((unsigned)e, mC);
-        exreg[i] = xin[(m0 + po) * ldxi + (e - po * C)];
-      }
-#pragma unroll
-      for (int i = 0; i < EWMAX; ++i) ewreg[i] = Wfp[min(tid + 256 * i, C * C - 1)];
+    for (int i = 0; i < EXMAX; ++i) {
+      const int e = min(tid + 256 * i, nzq * C - 1);
+      const int po = (int)__umulhi((unsigned)e, mC);
+      exreg[i] = xin[(m0 + po) * ldxi + (e - po * C)];
     }
+#pragma unroll
+    for (int i = 0; i < EWMAX; ++i) ewreg[i] = Wfp[min(tid + 256 * i, C * C - 1)];
+  };
+  if (LV && EARLY_PF) prefetch_epi();
   save_rows(reinterpret_cast<__bf16*>(c_ga1));
   stamp(8);
 
@@ -647,7 +652,15 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       if (s.additive) e3a = es3n[jn];
       else { e3a = es3n[2 * jn]; e3b = es3n[2 * jn + 1]; }
     }
-    {   // x_in and Wf, requested before dgrad1, into the scratch
+    if (!EARLY_PF) prefetch_epi();
+    // g_z1 = (dL/dz1 of the step's output) + dgrad1, the four waves' partial sums in the order the stand-alone kernel adds them
+    for (int idx = tid; idx < NPX * Ch; idx += 256) {
+      const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
+      const float* p = R3 + po * NP + n;
+      const float d = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
+      if (po < nzp) GZl[po * XS + n] += d;
+    }
+    {   // x_in and Wf into the scratch
       const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
 #pragma unroll
       for (int i = 0; i < EXMAX; ++i) {
@@ -666,13 +679,6 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         }
       }
     }
-    // g_z1 = (dL/dz1 of the step's output) + dgrad1, the four waves' partial sums in the order the stand-alone kernel adds them
-    for (int idx = tid; idx < NPX * Ch; idx += 256) {
-      const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
-      const float* p = R3 + po * NP + n;
-      const float d = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
-      if (po < nzp) GZl[po * XS + n] += d;
-    }
     __syncthreads();
     // g_x = Wf^T g_z: thread (pixel p of a pass, outputs 4 og .. 4 og + 3), input channels ascending (chanmix_body)
     {
@@ -683,7 +689,8 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         for (int pp = p; pp < NPX; pp += TP) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const float* xr = GZl + pp * XS;
-          for (int c = 0; c < C; ++c) {
+#pragma unroll 4
+          for (int c = 0; c < C; ++c) {   // (C % 4 == 0: four channels' LDS reads in flight before their FMAs)
             const float xv = xr[c];
             const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp4 + o);
 #pragma unroll
@@ -694,6 +701,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
           if (gxo && pp < nzp) *reinterpret_cast<f32x4*>(gxo + (mt0 + pp) * C + o) = acc;   // C % 4 == 0 (host check)
         }
     }
+    stamp(10);
     // partial (g_z x_in^T, sum g_z) of this workgroup: one slab of the step's mix_part
     {
       const int E = C * C + C;
@@ -703,17 +711,21 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         float sm_ = 0.f;
         if (idx < C * C) {
           const int o = (int)__umulhi((unsigned)idx, mC), c = idx - o * C;
+#pragma unroll 8
           for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o] * XIl[q * XS + c];
         } else {
           const int o = idx - C * C;
+#pragma unroll 8
           for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o];
         }
         part[idx] = sm_;
       }
     }
+    stamp(11);
     if (below) {
       // -------------------------------------------------------------- 7. coupling backward of step k - 1 on the tile
       __syncthreads();   // g_x is complete; the partial sums above are done with GZl (overwritten below in a run)
+      stamp(12);
       float* __restrict__ gan = a.ga + (long)(k - 1) * a.ga_stride + mt0 * Cout;   // g_a3 of step k - 1 (the weight gradients read it too)
       float* __restrict__ gzn = a.gz[(k - 1) & 1] + mt0 * C;
       float sb0 = 0.f, sl0 = 0.f, sb1 = 0.f, sl1 = 0.f;
@@ -760,6 +772,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
           gzn[po * C + n] = GXl[po * XS + n];
         }
       }
+      stamp(13);
       __syncthreads();
       if (MULTI) {
         if (gn < Gn) {
@@ -778,6 +791,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       float* prow = a.tailpart + ((long)(k - 1) * 256 + blockIdx.x) * 2 * Cout;
       for (int jj = tid; jj < C2n; jj += 256) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll 4
         for (int gg = 0; gg < Gn; ++gg) {
           const float* row = Al + (long)gg * 4 * C2n;
           t0 += row[jj]; t1 += row[C2n + jj]; t2 += row[2 * C2n + jj]; t3 += row[3 * C2n + jj];
@@ -789,6 +803,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         }
       }
     }
+    stamp(14);
     if (MULTI && k > k_last) __syncthreads();   // the next step's staging overwrites what the epilogue read
   }
   }   // steps of the level
@@ -953,6 +968,7 @@ int fusedb_level_launch(const FusedLevelCall& c, hipStream_t st, int* grid_used)
   a.lv = c.lv;
   a.gz[0] = c.gz[0]; a.gz[1] = c.gz[1]; a.tailpart = c.tailpart;
   a.ga = c.ga; a.ga_stride = c.ga_stride; a.o_ga2 = c.o_ga2; a.o_ga1 = c.o_ga1; a.o_x3 = c.o_x3;
+  a.c.stamps = c.stamps;
   if (grid_used) *grid_used = grid;
   const double M = (double)s.B * s.H * s.W;
   const int cls = NFK_PROF_FUSED_BWD + (M >= 8192 ? 0 : (M >= 2048 ? 1 : 2));

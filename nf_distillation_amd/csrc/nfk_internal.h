@@ -259,6 +259,7 @@ struct FusedLevelCall {
   nfk_level_bwd lv;
   nfk_step2d first;
   float* gz[2]; float* tailpart; float* ga; long ga_stride, o_ga2, o_ga1, o_x3;
+  unsigned long long* stamps;   // diagnostic: [grid][16] cycle stamps of the last step of the last launch (null in production)
 };
 int fusedb_level_ok(const nfk_step2d& s);      // 1: level mode covers this geometry; 2: also as ONE launch for all steps
 int fusedb_level_grid(const nfk_step2d& s);    // workgroups of a step launch (what the one-launch form uses may differ: see fusedb_level_launch)

@@ -28,6 +28,7 @@ def _cfg(K, **kw):
 
 def _grads(cfg, B, seed, mode, hints):
     import nf_distillation_amd as nfa
+    torch.manual_seed(1234)   # (the `shuffle` permutation is drawn at construction and is not part of the state_dict)
     m = nfa.create_glow_model(cfg)
     m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), 11))
     m = m.cuda().set_compute_dtype("bf16")
