@@ -22,6 +22,7 @@
 // B = 64) made a round trip through HBM each, re-read once per tap by the narrow dgrad, plus the 2 x 16.8 MB of h1 / h2
 // their epilogues read.
 #include "nfk_internal.h"
+#include <type_traits>
 
 namespace nfk {
 
@@ -617,6 +618,11 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     stamp(10);
   } else {
     // ---------------------------------------------------------------- 6. level mode: channel-mix backward on the tile
+    // (the thread index passes through an empty asm once more: what the epilogue derives from it -- addresses, pixel and
+    //  channel indices -- is then computed HERE; hoisted to the top of the step it was spilled there and came back through
+    //  sixty scratch loads, each a round trip of its own behind the weight stream's loads)
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
     const int C2n = C - Ch, Gn = 256 / C2n, G4 = Cp4 / 4;
     const bool below = k > a.lv.k_lo;   // the coupling backward of step k - 1 rides along
     CStep* spn = (CStep*)(a.lv.steps + (below ? k - 1 : k));
@@ -628,7 +634,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       load_masks(reinterpret_cast<const unsigned char*>(a.lv.masks) + (long)max(k - 1, k_last) * a.lv.mask_stride);
       load_es_w3(spq->es2, spq->es1, spq->wg3);
     }
-    const int jn = tid % C2n, gn = tid / C2n;
+    const int jn = tq % C2n, gn = tq / C2n;
     const long mt0 = (long)b0 * HW + (long)row0 * W;   // first pixel of the tile (its pixels are contiguous in [M])
     const int nzp = min(s.B - b0, TS) * R * W;         // ... and how many of them exist
     // operands of the coupling backward below: (shift | scale) rows and z2 of step k - 1, requested before the mat-vec
@@ -654,7 +660,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
     }
     if (!EARLY_PF) prefetch_epi();
     // g_z1 = (dL/dz1 of the step's output) + dgrad1, the four waves' partial sums in the order the stand-alone kernel adds them
-    for (int idx = tid; idx < NPX * Ch; idx += 256) {
+    for (int idx = tq; idx < NPX * Ch; idx += 256) {
       const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
       const float* p = R3 + po * NP + n;
       const float d = (p[0] + p[NPX * NP]) + (p[2 * NPX * NP] + p[3 * NPX * NP]);
@@ -664,7 +670,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
 #pragma unroll
       for (int i = 0; i < EXMAX; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tq + 256 * i;
         if (e < NPX * C) {
           const int po = (int)__umulhi((unsigned)e, mC);
           XIl[po * XS + (e - po * C)] = (e < nzp * C) ? exreg[i] : 0.f;
@@ -672,7 +678,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < EWMAX; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tq + 256 * i;
         if (idx < C * C) {
           const int r = (int)__umulhi((unsigned)idx, mC);
           Wl[r * Cp4 + (idx - r * C)] = ewreg[i];   // Wm[r][q]: in = r, out = q (chanmix_body, trans)
@@ -680,45 +686,93 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
       }
     }
     __syncthreads();
-    // g_x = Wf^T g_z: thread (pixel p of a pass, outputs 4 og .. 4 og + 3), input channels ascending (chanmix_body)
+    // g_x = Wf^T g_z: thread (pixel p of a pass, outputs 4 og .. 4 og + 3), input channels ascending (chanmix_body); two
+    // passes' pixels side by side, so that a 16-byte row piece of Wf read from LDS feeds both (the phase is bound by LDS reads)
     {
       const int TP = 256 / G4 < NPX ? (256 / G4) : NPX;
-      const int p = tid / G4, og = tid - p * G4, o = og * 4;
+      const int p = tq / G4, og = tq - p * G4, o = og * 4;
       float* gxo = (k == a.lv.k_lo) ? a.lv.g_x : nullptr;
       if (p < TP)
-        for (int pp = p; pp < NPX; pp += TP) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int pp = p; pp < NPX; pp += 2 * TP) {
+          const int p2 = pp + TP < NPX ? pp + TP : pp;   // (no second pixel: the first once more, result discarded)
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
           const float* xr = GZl + pp * XS;
+          const float* xr2 = GZl + p2 * XS;
 #pragma unroll 4
           for (int c = 0; c < C; ++c) {   // (C % 4 == 0: four channels' LDS reads in flight before their FMAs)
-            const float xv = xr[c];
+            const float xv = xr[c], xv2 = xr2[c];
             const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + c * Cp4 + o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+            for (int r = 0; r < 4; ++r) { acc[r] += w[r] * xv; acc2[r] += w[r] * xv2; }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) GXl[pp * XS + o + r] = acc[r];
           if (gxo && pp < nzp) *reinterpret_cast<f32x4*>(gxo + (mt0 + pp) * C + o) = acc;   // C % 4 == 0 (host check)
+          if (p2 != pp) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) GXl[p2 * XS + o + r] = acc2[r];
+            if (gxo && p2 < nzp) *reinterpret_cast<f32x4*>(gxo + (mt0 + p2) * C + o) = acc2;
+          }
         }
     }
     stamp(10);
-    // partial (g_z x_in^T, sum g_z) of this workgroup: one slab of the step's mix_part
+    // partial (g_z x_in^T, sum g_z) of this workgroup: one slab of the step's mix_part.  A small register-tiled product:
+    // thread (to, tc) owns a T x T block of (o, c) pairs -- 2 T LDS reads per T^2 multiply-adds instead of 2 per 1; pixels
+    // in ascending order per element, as the one-element-per-thread loop (and chanmix_body) adds them
     {
       const int E = C * C + C;
-      const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
       float* part = ((CGrads*)(a.lv.grads + k))->mix_part + (long)blockIdx.x * E;
-      for (int idx = tid; idx < E; idx += 256) {
-        float sm_ = 0.f;
-        if (idx < C * C) {
-          const int o = (int)__umulhi((unsigned)idx, mC), c = idx - o * C;
-#pragma unroll 8
-          for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o] * XIl[q * XS + c];
-        } else {
-          const int o = idx - C * C;
-#pragma unroll 8
-          for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o];
+      auto tiled = [&](auto tt) {
+        constexpr int T = decltype(tt)::value;
+        const int nT = C / T, to = tq / nT, tc = tq - to * nT;
+        if (to >= nT) return;
+        float acc[T][T], cs[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          cs[i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < T; ++j) acc[i][j] = 0.f;
         }
-        part[idx] = sm_;
+        const float* gzp = GZl + to * T;
+        const float* xip = XIl + tc * T;
+#pragma unroll 4
+        for (int q = 0; q < NPX; ++q) {
+          float gv[T], xv[T];
+#pragma unroll
+          for (int i = 0; i < T; ++i) { gv[i] = gzp[q * XS + i]; xv[i] = xip[q * XS + i]; }
+#pragma unroll
+          for (int i = 0; i < T; ++i) {
+            cs[i] += gv[i];
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[i][j] += gv[i] * xv[j];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+#pragma unroll
+          for (int j = 0; j < T; ++j) part[(to * T + i) * C + tc * T + j] = acc[i][j];
+          if (tc == 0) part[C * C + to * T + i] = cs[i];
+        }
+      };
+      const int T = (C + 15) / 16;
+      if (T == 1 && C * C <= 256) tiled(std::integral_constant<int, 1>{});
+      else if (T == 2 && (C & 1) == 0 && (C / 2) * (C / 2) <= 256) tiled(std::integral_constant<int, 2>{});
+      else if (T == 3 && C % 3 == 0 && (C / 3) * (C / 3) <= 256) tiled(std::integral_constant<int, 3>{});
+      else {
+        const unsigned mC = 0xFFFFFFFFu / (unsigned)C + 1u;
+        for (int idx = tq; idx < E; idx += 256) {
+          float sm_ = 0.f;
+          if (idx < C * C) {
+            const int o = (int)__umulhi((unsigned)idx, mC), c = idx - o * C;
+#pragma unroll 8
+            for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o] * XIl[q * XS + c];
+          } else {
+            const int o = idx - C * C;
+#pragma unroll 8
+            for (int q = 0; q < NPX; ++q) sm_ += GZl[q * XS + o];
+          }
+          part[idx] = sm_;
+        }
       }
     }
     stamp(11);
@@ -767,7 +821,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         row[jn] = sb0; row[C2n + jn] = sl0; row[2 * C2n + jn] = sb1; row[3 * C2n + jn] = sl1;
       }
       if (!MULTI) {   // dL/dz1 of step k - 1 = g_x's first half, beside g_z2 in the same rows
-        for (int idx = tid; idx < nzp * Ch; idx += 256) {
+        for (int idx = tq; idx < nzp * Ch; idx += 256) {
           const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
           gzn[po * C + n] = GXl[po * XS + n];
         }
@@ -782,14 +836,14 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
             if (pp < NPX) GZl[pp * XS + Ch + jn] = gz2n[e];
           }
         }
-        for (int idx = tid; idx < NPX * Ch; idx += 256) {
+        for (int idx = tq; idx < NPX * Ch; idx += 256) {
           const int po = (int)__umulhi((unsigned)idx, mCh), n = idx - po * Ch;
           GZl[po * XS + n] = GXl[po * XS + n];
         }
       }
       // one partial row per workgroup: (sum g_a3, 3 sum g_h h), groups added in fixed order
       float* prow = a.tailpart + ((long)(k - 1) * 256 + blockIdx.x) * 2 * Cout;
-      for (int jj = tid; jj < C2n; jj += 256) {
+      for (int jj = tq; jj < C2n; jj += 256) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll 4
         for (int gg = 0; gg < Gn; ++gg) {
