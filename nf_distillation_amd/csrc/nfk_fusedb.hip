@@ -515,10 +515,9 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
   float* const Al = Wl + C * Cp4;                    // [256 / C2][4][C2] column sums of the coupling backward
   float* const GZl = reinterpret_cast<float*>(smem_fb + g.oGZ);   // [NPX][XS] dL/dz on the tile
   // level mode: the epilogue's operands -- the step's input rows on the tile (x_in: the other factor of the partial
-  // g_z x^T) and Wf.  Requested before dgrad1 and travelling under it where the registers allow (21 more live values);
-  // the 96-pixel tiles of a level with halo rows are at the limit already (scratch traffic shares the vector-memory
-  // queue with the weight stream): there they are requested at the start of the epilogue
-  constexpr bool EARLY_PF = MT32 < 3;
+  // g_z x^T) and Wf -- are requested before dgrad1 and travel under it (21 more live values; requested at the start of the
+  // epilogue they cost the level-1 step a full round trip behind the g_a1 rows' stores: 20 k cycles)
+  constexpr bool EARLY_PF = true;
   auto prefetch_epi = [&]() {
     const float* xin = k == 0 ? a.lv.x0 : a.lv.zout + (long)(k - 1) * a.lv.zout_stride;
     const int ldxi = k == 0 ? a.lv.ldx0 : C;
