@@ -137,8 +137,12 @@ typedef struct nfk_repack_desc {
   void *wf;       /* bf16 repack only, may be NULL: fragment-ordered copy of wt (Kp = nfk_padded_k_bf16(taps*Cin)) */
   void *wg;       /* bf16 repack only, may be NULL: fragment-ordered copy of wd (rows = Cin, Kp = nfk_padded_k_bf16(taps*Cout)),
                    * layout `gfrag` as `frag`; for gfrag = 2 the rows behind Cin are NOT written (keep the buffer zeroed) */
-  int32_t gfrag, pad_;
+  int32_t gfrag;
+  int32_t flags;  /* bf16 repack only.  NFK_REPACK_FRAG_ONLY: the row-major copies wt / wd are not written where a fragment-
+                   * ordered copy of the same weights (wf / wg) is -- for models whose every step runs the fused kernels, which
+                   * read the latter only (the reverse pass and the per-conv launches read wt / wd: repack without the flag) */
 } nfk_repack_desc;
+#define NFK_REPACK_FRAG_ONLY 1
 
 typedef struct nfk_small_grad_args {
   const float *col1, *col2, *tail;

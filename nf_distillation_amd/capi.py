@@ -132,7 +132,10 @@ class KdGrads(C.Structure):
 class RepackDesc(C.Structure):
     _fields_ = [("w", c_fp), ("wt", c_fp), ("wd", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
                 ("taps", C.c_int32), ("frag", C.c_int32), ("wf", c_fp), ("wg", c_fp), ("gfrag", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("flags", C.c_int32)]
+
+
+REPACK_FRAG_ONLY = 1   # NFK_REPACK_FRAG_ONLY
 
 
 i32, f32, u64, vp, lng = C.c_int, C.c_float, C.c_size_t, C.c_void_p, C.c_long

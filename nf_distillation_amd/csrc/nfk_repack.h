@@ -71,6 +71,7 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
   __bf16* wg = (d.wd && d.gfrag) ? reinterpret_cast<__bf16*>(d.wg) : nullptr;
+  const bool fonly = (d.flags & NFK_REPACK_FRAG_ONLY) != 0;
   for (int t = bx * nthr + tid; t < n8_f + n8_d + n8_g; t += nbx * nthr) {
     float v[8];
     __bf16* dst;
@@ -116,6 +117,8 @@ __device__ __forceinline__ void repack_gather_bf16(const nfk_repack_desc& d, con
         *reinterpret_cast<rp_u32x4*>(wg + ug * 8) = pkg;
       }
     }
+    // (fragment-only repack: the row-major copies are skipped where their fragment-ordered twins exist)
+    if (fonly && ((t < n8_f && n8_g > 0) || (t >= n8_f + n8_g && wg))) continue;
     const rp_u32x4 pk = {rp_pack2(v[0], v[1]), rp_pack2(v[2], v[3]), rp_pack2(v[4], v[5]), rp_pack2(v[6], v[7])};
     *reinterpret_cast<rp_u32x4*>(dst) = pk;
   }
@@ -134,6 +137,8 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
   __bf16* wd = reinterpret_cast<__bf16*>(d.wd);
   __bf16* wf = reinterpret_cast<__bf16*>(d.wf);
   __bf16* wg = (d.wd && d.gfrag) ? reinterpret_cast<__bf16*>(d.wg) : nullptr;
+  const bool fonly = (d.flags & NFK_REPACK_FRAG_ONLY) != 0;
+  const bool put_wt = !(fonly && have_wf), put_wd = !(fonly && wg);   // the row-major copies: skipped where a fragment copy exists
   const unsigned mCin = 0xFFFFFFFFu / (unsigned)Cin + 1u, mCout = 0xFFFFFFFFu / (unsigned)Cout + 1u;   // n / C for n < 2^16
   // the trip count is the same for every worker of the weight (barriers are workgroup-wide, and a workgroup may hold
   // two workers): a worker without a tile in the last trip runs it with an empty tile
@@ -166,7 +171,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
         if (++ci == Cin) { ci = 0; ++tap; }
       }
       const rp_u32x4 pk = {rp_pack2(v[0], v[1]), rp_pack2(v[2], v[3]), rp_pack2(v[4], v[5]), rp_pack2(v[6], v[7])};
-      if (co < Cout) *reinterpret_cast<rp_u32x4*>(wt + (long)co * Kp + k0) = pk;
+      if (co < Cout && put_wt) *reinterpret_cast<rp_u32x4*>(wt + (long)co * Kp + k0) = pk;
       if (have_wf) {
         long u;
         if (d.frag == 1) u = ((long)((co >> 5) * (Kp / 16) + (k0 >> 4)) << 6) + (co & 31) + 32 * ((k0 >> 3) & 1);
@@ -192,7 +197,7 @@ __device__ __forceinline__ void repack_tiles_bf16(const nfk_repack_desc& d, cons
           if (++co == Cout) { co = 0; ++tap; }
         }
         const rp_u32x4 pk = {rp_pack2(v[0], v[1]), rp_pack2(v[2], v[3]), rp_pack2(v[4], v[5]), rp_pack2(v[6], v[7])};
-        *reinterpret_cast<rp_u32x4*>(wd + (long)ci * Kpd + k0) = pk;
+        if (put_wd) *reinterpret_cast<rp_u32x4*>(wd + (long)ci * Kpd + k0) = pk;
         if (wg) {
           long ug;
           if (d.gfrag == 1) ug = ((long)((ci >> 5) * (Kpd / 16) + (k0 >> 4)) << 6) + (ci & 31) + 32 * ((k0 >> 3) & 1);

@@ -328,6 +328,22 @@ class FlowEngine:
                                      else capi.struct_array_to_device([q.cs for q in recs[i:j]], device))}
                 i = j
 
+        # every step on the fused kernels (forward and, where it trains, backward): they read the fragment-ordered weight
+        # copies only, so the per-forward repack can leave the row-major ones out (the reverse pass and the per-conv
+        # launches read those: _refresh repacks in full for them)
+        steps_ = [q for q in recs if q.kind == "step"]
+        all_fused = bool(self.bf16 and not self.is_1d and steps_) and all(
+            q.cs.wf1 and lib.nfk_step2d_fused_tiles(C.byref(q.cs)) > 0 and
+            (not any(p.requires_grad for p in q.mod.parameters()) or (q.cs.wg1 and lib.nfk_step2d_fused_bwd_ok(C.byref(q.cs))))
+            for q in steps_)
+        step_repack_frag_dev = None
+        if all_fused:
+            for rd in step_repack:
+                rd.flags = capi.REPACK_FRAG_ONLY
+            step_repack_frag_dev = capi.struct_array_to_device(step_repack, device)
+            for rd in step_repack:
+                rd.flags = 0
+
         self.state = {
             "runs": runs, "levels": levels,
             "B": B, "recs": recs, "prep_buf": prep_buf, "pack_buf": pack_buf, "keep": keep,
@@ -335,6 +351,7 @@ class FlowEngine:
             "prep_host": prep_descs,
             "repack_dev": capi.struct_array_to_device(repack_descs, device), "n_repack": len(repack_descs),
             "step_repack_dev": capi.struct_array_to_device(step_repack, device), "n_step_repack": len(step_repack),
+            "step_repack_frag_dev": step_repack_frag_dev, "has_plain": False,
             "step_buf": step_buf,
             "any_dense": any_dense, "version": None, "has_inverse": False, "sig": self._signature(),
             "out_shape": (Cc, H, W), "grad_sig": None, "grad_dev": None,
@@ -356,17 +373,24 @@ class FlowEngine:
         """Run prep (+ repack) if parameters may have changed since the cached products were made."""
         trainable = any(p.requires_grad for p in self.params())
         ver = self._version()
-        fresh = (not trainable) and st["version"] == ver and (st["has_inverse"] or not want_inverse)
+        # row-major weight copies: read by the reverse pass and by every path but the fused forward / fused backward
+        want_plain = bool(want_inverse or st["step_repack_frag_dev"] is None or not self.fused or
+                          self.bwd_mode not in (capi.BWD_DEFAULT, capi.BWD_FUSED))
+        fresh = ((not trainable) and st["version"] == ver and (st["has_inverse"] or not want_inverse) and
+                 (st["has_plain"] or not want_plain))
         if fresh:
             return
         lib, s = capi.lib(), capi.stream()
         if self.bf16:   # one launch: prep of every step, the Split2d convs (f32) and the coupling nets' convs (bf16)
+            rp = st["step_repack_dev"] if want_plain else st["step_repack_frag_dev"]
             check(lib.nfk_prep_repack(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, ptr(st["repack_dev"]),
-                                      st["n_repack"], ptr(st["step_repack_dev"]), st["n_step_repack"], s), "nfk_prep_repack")
+                                      st["n_repack"], ptr(rp), st["n_step_repack"], s), "nfk_prep_repack")
+            st["has_plain"] = want_plain
         else:
             check(lib.nfk_prep(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, s), "nfk_prep")
             check(lib.nfk_repack_batch(ptr(st["repack_dev"]), st["n_repack"], s), "nfk_repack_batch")
             check(lib.nfk_repack_batch(ptr(st["step_repack_dev"]), st["n_step_repack"], s), "nfk_repack_batch(step convs)")
+            st["has_plain"] = True
         st["version"], st["has_inverse"] = ver, bool(want_inverse)
 
     # ------------------------------------------------------------------ public entry points
