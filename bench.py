@@ -140,6 +140,9 @@ class Leg:
         if args.fused_runs is not None:
             self.teacher.flow.engine().fused_runs = args.fused_runs in ("both", "teacher")
             self.student.flow.engine().fused_runs = args.fused_runs in ("both", "student")
+        if args.level_backward is not None:   # experiment knob: 0 per-step calls, 1 per level / one launch per step, 2 + runs, 3 + aux
+            e = self.student.flow.engine()
+            e.level_backward, e.level_multi, e.level_wgrad_aux = args.level_backward >= 1, args.level_backward >= 2, args.level_backward >= 3
         self.step = DistillationStep(self.student, self.teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
         if not args.no_overlap:
             self.step.enable_concurrency()  # teacher fwd || student fwd, wgrad || dgrad on side streams
@@ -160,6 +163,8 @@ class Leg:
             from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep
             cls = AheadPipelinedStep if kind == "ahead" else PipelinedStep
             runner = cls(self.step, data[0], strict=True)
+            if getattr(a, "phase_lock", None) is not None:
+                runner.phase_lock = bool(a.phase_lock)
             if getattr(a, "teacher_start_layer", None) is not None:   # experiment knob (-1: fork at the start of the call)
                 runner.teacher_starts_after_layer = None if a.teacher_start_layer < 0 else a.teacher_start_layer
             runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
@@ -343,6 +348,12 @@ def main():
     ap.add_argument("--fused-runs", choices=("both", "teacher", "student", "off"), default=None,
                     help="experiment knob: which model walks a whole level's FlowSteps in ONE launch (levels 2 / 3; "
                          "default: the engines' default)")
+    ap.add_argument("--level-backward", type=int, default=None, choices=(0, 1, 2, 3),
+                    help="experiment knob: the student's bf16 backward -- 0 per-step calls, 1 per level with one launch per step, "
+                         "2 with runs of steps in one launch, 3 with the per-level launches on the auxiliary stream (default: the engine's)")
+    ap.add_argument("--phase-lock", type=int, default=None, choices=(0, 1),
+                    help="experiment knob: PipelinedStep.phase_lock (level-1 phases of the two chains one after the other, their "
+                         "deep-level phases beside each other)")
     ap.add_argument("--teacher-start-layer", type=int, default=None,
                     help="experiment knob: student layer after which the pipelined teacher branch is forked (-1: at once)")
     ap.add_argument("--tune", type=int, nargs="*", default=None, metavar="KNOB VALUE",

@@ -28,6 +28,16 @@ import torch
 from .training import DistillationStep, distillation_loss
 
 
+def _last_step_of_first_level(model):
+    """Index of the last layer before the first Split2d (the last FlowStep of level 1); the last layer if there is none."""
+    from .modules import Split2d
+    layers = list(model.flow.layers)
+    for i, l in enumerate(layers):
+        if isinstance(l, Split2d):
+            return i - 1
+    return len(layers) - 1
+
+
 class PipelinedStep:
     def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2, with_noise=False, strict=False):
         self.strict = strict    # True: a failed capture raises instead of degrading to eager execution
@@ -67,6 +77,11 @@ class PipelinedStep:
         # level-1 launches do not meet, LOSES 2.6 % (after the second level: 7.5 %) -- the teacher's chain then ends later
         # than the student's backward can use the freed CUs
         self.teacher_starts_after_layer = None
+        # Phase lock (experiment, bench.py --phase-lock): the two chains' launches come in two kinds -- level 1 wants every
+        # CU (256 workgroups, one per CU), the deep levels run for long on 64.  Side by side, a 256-workgroup launch beside a
+        # 64-CU run takes two rounds on the 192 free CUs: twice its time.  Locked: student level 1 -> teacher level 1 (each
+        # alone on the chip) -> both deep phases beside each other (64 + 64 CUs) -> the student's level-1 backward.
+        self.phase_lock = False
 
     # ------------------------------------------------------------------ the two branches
     def _teacher_branch(self):
@@ -118,17 +133,32 @@ class PipelinedStep:
         self._handover()   # what the previous call prepared
         box = {}
 
+        teng = self.step.teacher.flow.engine() if hasattr(self.step.teacher, "flow") else None
+
         def start_teacher():
             fork = torch.cuda.Event()
             fork.record(main)
             self.side.wait_event(fork)
             with torch.cuda.stream(self.side):
-                self._teacher_branch()
+                if self.phase_lock and teng is not None:
+                    def l1_done():
+                        box["t_l1"] = torch.cuda.Event()
+                        box["t_l1"].record(self.side)
+                    teng.layer_hooks = {_last_step_of_first_level(self.step.teacher): l1_done}
+                try:
+                    self._teacher_branch()
+                finally:
+                    if teng is not None:
+                        teng.layer_hooks = {}
                 box["join"] = torch.cuda.Event()
                 box["join"].record(self.side)
+            if "t_l1" in box:
+                main.wait_event(box["t_l1"])   # the student's deep levels start when the teacher's level 1 has left the chip
 
         seng = self.step.student.flow.engine() if hasattr(self.step.student, "flow") else None
         k = self.teacher_starts_after_layer
+        if self.phase_lock and seng is not None:
+            k = _last_step_of_first_level(self.step.student)
         if seng is None or k is None:
             start_teacher()
             out = self._student_fwd_bwd()
