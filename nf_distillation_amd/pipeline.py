@@ -82,6 +82,11 @@ class PipelinedStep:
         # 64-CU run takes two rounds on the 192 free CUs: twice its time.  Locked: student level 1 -> teacher level 1 (each
         # alone on the chip) -> both deep phases beside each other (64 + 64 CUs) -> the student's level-1 backward.
         self.phase_lock = False
+        # Order in which the two branches' launches are enqueued (and their graph nodes created).  A replayed hipGraph is fed
+        # to the hardware queues node by node in creation order, at a rate the host sets -- not all at once: with the
+        # teacher's ~45 nodes created first the student's chain, which IS the step's critical path, saw its first kernel
+        # ~0.75 ms after the teacher's (rocprofv3 timeline, profiles/r03_timeline_*.txt).  True: the student's nodes first.
+        self.student_first = False
 
     # ------------------------------------------------------------------ the two branches
     def _teacher_branch(self):
@@ -159,7 +164,18 @@ class PipelinedStep:
         k = self.teacher_starts_after_layer
         if self.phase_lock and seng is not None:
             k = _last_step_of_first_level(self.step.student)
-        if seng is None or k is None:
+        if self.student_first:
+            # the teacher's branch still forks from the START of the call (the event is recorded here), but its launches are
+            # ENQUEUED -- and, in a captured graph, created -- after the student's: see student_first in __init__
+            fork0 = torch.cuda.Event()
+            fork0.record(main)
+            out = self._student_fwd_bwd()
+            self.side.wait_event(fork0)
+            with torch.cuda.stream(self.side):
+                self._teacher_branch()
+                box["join"] = torch.cuda.Event()
+                box["join"].record(self.side)
+        elif seng is None or k is None:
             start_teacher()
             out = self._student_fwd_bwd()
         else:
