@@ -394,7 +394,7 @@ class FlowEngine:
         st["version"], st["has_inverse"] = ver, bool(want_inverse)
 
     # ------------------------------------------------------------------ public entry points
-    def encode(self, x, y_onehot, logdet, noise=None, keep=None):
+    def encode(self, x, y_onehot, logdet, noise=None, keep=None, hints_only=False):
         """-> (list of every layer's output, logdet).  `keep` (optional, honoured by passes that record no gradient): the
         layer indices whose outputs the caller will read (the KD hint layers of pl_module.py:262-282; negative indices
         allowed; the last layer is always kept) -- the other entries of the list are None and never reach HBM where a
@@ -409,7 +409,12 @@ class FlowEngine:
             n_layers = len(self.layers)
             keep = frozenset(int(k) % n_layers for k in keep) | {n_layers - 1}
         # (inside autograd.Function.forward the grad mode is always off: whether this pass records gradients is read here)
-        res = _EncodeFn.apply(self, x, logdet, noise, y_onehot, (keep, torch.is_grad_enabled()), *self.params())
+        # hints_only (with `keep`, passes that record no gradient): the caller reads the kept layer outputs and nothing else
+        # -- the frozen teacher of the distillation step (pl_module.py:216-225 discards its bits/dim).  Split2d then only
+        # passes z1 on (no prior convolution, no log-density) and the log-det partials are never summed; the returned logdet
+        # is meaningless.
+        res = _EncodeFn.apply(self, x, logdet, noise, y_onehot, (keep, torch.is_grad_enabled(), bool(hints_only and keep is not None)),
+                              *self.params())
         return list(res[:-1]), res[-1]
 
     def decode(self, z, y_onehot, temperature, eps=None):
@@ -739,10 +744,11 @@ class _EncodeFn(torch.autograd.Function):
         eng._refresh(st, False)
         lib, s = capi.lib(), capi.stream()
         B, dev = x.shape[0], x.device
-        keep, grad_mode = keep_and_mode
+        keep, grad_mode, hints_only = keep_and_mode
         need = grad_mode and any(ctx.needs_input_grad)   # under torch.no_grad() nothing is kept for a backward
         if need:
             keep = None   # a pass that will be differentiated keeps every layer's output
+            hints_only = False
         ctx.set_materialize_grads(False)
         ctx.eng, ctx.need, ctx.B, ctx.st = eng, need, B, st
         ld = logdet.to(torch.float32).contiguous()
@@ -760,6 +766,7 @@ class _EncodeFn(torch.autograd.Function):
 
         scratch = _Scratch(st, dev)
         cur, cur_ld = None, None  # NHWC tensor of the running activation
+        cur_stride = None         # row length of `cur` in floats when it is a channel slice of a wider tensor (hints_only)
         run, keep_alive = None, []
         lv_saved = {}   # {index of a level's last FlowStep: its strided arenas}: the backward of a whole level (nfk_level2d_bwd)
         skip_until = 0
@@ -857,7 +864,8 @@ class _EncodeFn(torch.autograd.Function):
                         xs = _nhwc(x)
                         check(lib.nfk_squeeze(ptr(xs), r.C, None, ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_squeeze")
                 else:
-                    check(lib.nfk_squeeze(ptr(cur), r.C, None, ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_squeeze")
+                    check(lib.nfk_squeeze(ptr(cur), cur_stride or r.C, None, ptr(out), B, r.C, r.H, r.W, 0, s), "nfk_squeeze")
+                    cur_stride = None
                 saved.append(None)
             elif r.kind == "step" and eng.fused and eng.bf16 and lib.nfk_step2d_fused_tiles(C.byref(r.cs)) > 0:
                 # ---- fused path: one launch per step; the log-det is accumulated once per run of steps
@@ -960,6 +968,13 @@ class _EncodeFn(torch.autograd.Function):
                 check(lib.nfk_step2d_fwd(C.byref(r.cs), ptr(cur), r.C, ptr(ld), ptr(zb), ptr(h1), ptr(h2), ptr(hs),
                                          ptr(ws), ptr(out), ptr(ld_out), s), "nfk_step2d_fwd")
                 ld = ld_out
+            elif (hints_only and r.idx not in keep and r.idx + 1 < len(st["recs"]) and st["recs"][r.idx + 1].kind == "squeeze"
+                  and cur is not None):
+                # hints-only pass: Split2d passes z1 = the first half of the channels on; the squeeze that follows reads it in
+                # place, with the full rows' stride
+                out = cur[..., : r.C // 2]
+                cur_stride = r.C
+                saved.append(None)
             else:  # split
                 if cur is None:
                     cur = _nhwc(x)
@@ -986,7 +1001,8 @@ class _EncodeFn(torch.autograd.Function):
                 eng.first_layer_hook()  # the model input has been consumed (and dequantised in place)
             if r.idx in eng.layer_hooks:
                 eng.layer_hooks[r.idx]()
-        ld = flush_ld(ld)
+        if not hints_only:
+            ld = flush_ld(ld)
         ctx.saved = saved
         ctx.levels = lv_saved
         ctx.x_contig = x.is_contiguous()

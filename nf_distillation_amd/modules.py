@@ -365,8 +365,8 @@ class FlowNet(nn.Module):
             self._engine = FlowEngine(list(self.layers))
         return self._engine
 
-    def _encode_all(self, z, y_onehot, logdet, noise=None, keep=None):
-        return self.engine().encode(z, y_onehot, logdet, noise, keep)
+    def _encode_all(self, z, y_onehot, logdet, noise=None, keep=None, hints_only=False):
+        return self.engine().encode(z, y_onehot, logdet, noise, keep, hints_only)
 
     def _decode_all(self, z, y_onehot, temperature, eps=None):
         return self.engine().decode(z, y_onehot, temperature, eps)
@@ -452,18 +452,23 @@ class Glow(nn.Module):
         h = self._prior_tensor(batch, y_onehot)
         return split_feature(h, "split")
 
-    def forward(self, x=None, y_onehot=None, z=None, temperature=None, reverse=False, noise=None, eps=None, keep=None):
+    def forward(self, x=None, y_onehot=None, z=None, temperature=None, reverse=False, noise=None, eps=None, keep=None,
+                hints_only=False):
         """The reference's signature (models/flows.py:393-397) plus three optional extensions: `noise` / `eps` supply the
         dequantisation / Split2d draws, `keep` (no-grad passes) names the layer outputs the caller will read -- the KD hint
         indices of pl_module.py:262-282 -- so that the others are neither kept nor, where a level runs as one launch,
-        written to HBM at all (their entries in the returned list are None; the last layer is always there)."""
+        written to HBM at all (their entries in the returned list are None; the last layer is always there).  `hints_only`
+        (with `keep`, image flows, no gradient): the caller wants those outputs and nothing else -- the returned bits/dim
+        is None, and what only the likelihood needs (Split2d's prior convolution, the log-det sums, the prior) is not run."""
         if reverse:
             return self.reverse_flow(z, y_onehot, temperature, eps=eps)
         if keep is not None:
+            if hints_only and not self.is_1d and not self.y_condition and not torch.is_grad_enabled():
+                return self._forward_all(x, y_onehot, noise, keep, hints_only=True)
             return self.normal_flow(x, y_onehot, noise=noise, keep=keep)
         return self.normal_flow(x, y_onehot, noise=noise)
 
-    def _forward_all(self, x, y_onehot, noise, keep=None):
+    def _forward_all(self, x, y_onehot, noise, keep=None, hints_only=False):
         """Shared by Glow / GlowGetAllOutputs: returns (all outputs, bpd, y_logits)."""
         from .engine import prior_bpd
         capi.require_cuda(x, "x")
@@ -479,6 +484,9 @@ class Glow(nn.Module):
                 noise = torch.empty_like(x).uniform_(0, 1.0 / 256)
             logdet = torch.full((b,), -math.log(256.0) * c * h * w, device=x.device, dtype=torch.float32)
             dims = c * h * w
+        if hints_only:
+            outs, _ = self.flow._encode_all(x, y_onehot, logdet, noise, keep, hints_only=True)
+            return outs, None, None
         outs, objective_ld = self.flow._encode_all(x, y_onehot, logdet, noise, keep)
         last = outs[-1]
         prior_t = self._prior_tensor(b, y_onehot)

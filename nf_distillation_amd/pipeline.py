@@ -101,7 +101,7 @@ class PipelinedStep:
             teng.fused_split_inference = self.teacher_split
         try:
             with torch.no_grad():
-                t_z, _, _ = st.teacher(self.x_in, None, noise=self.nt_in, keep=st.t_idx)   # adds n_t(t+1) in place
+                t_z, _, _ = st.teacher(self.x_in, None, noise=self.nt_in, keep=st.t_idx, hints_only=True)   # adds n_t(t+1) in place
         finally:
             if teng is not None:
                 teng.fused_split_inference = prev

@@ -256,7 +256,7 @@ class DistillationStep:
         # KD-aware encode: of the teacher's 29 / 101 layer outputs the loss reads the hint layers only
         # (pl_module.py:262-282), so only those are materialised (the rest of the list is None)
         with torch.no_grad():
-            t_z, _, _ = self.teacher(x, y_onehot, noise=noise_teacher, keep=self.t_idx)
+            t_z, _, _ = self.teacher(x, y_onehot, noise=noise_teacher, keep=self.t_idx, hints_only=True)
         return t_z
 
     def perceptual_l1(self, x, latent=None, y_onehot=None):

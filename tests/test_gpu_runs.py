@@ -92,13 +92,16 @@ def test_kd_aware_encode_keeps_only_the_hint_layers(runs):
     with torch.no_grad():
         full, bpd_full, _ = model(x.clone().cuda(), None, noise=noise.cuda())
         part, bpd_part, _ = model(x.clone().cuda(), None, noise=noise.cuda(), keep=keep)
-    assert len(part) == len(full) == 101
+        hint, bpd_hint, _ = model(x.clone().cuda(), None, noise=noise.cuda(), keep=keep, hints_only=True)
+    assert len(part) == len(full) == len(hint) == 101
     assert torch.equal(bpd_full, bpd_part)
+    assert bpd_hint is None   # hints only: nothing of the likelihood is computed (no Split2d prior conv, no log-det sums)
     for i in range(101):
         if i in keep:
             assert torch.equal(part[i], full[i]), i
+            assert torch.equal(hint[i], full[i]), i
         else:
-            assert part[i] is None, i
+            assert part[i] is None and hint[i] is None, i
     # a pass that records gradients ignores `keep`: autograd may need any of the outputs
     student = build(cfg, sd)
     outs, _, _ = student(x.clone().cuda(), None, noise=noise.cuda(), keep=[-1])
