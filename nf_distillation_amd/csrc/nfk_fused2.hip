@@ -433,11 +433,7 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   // ------------------------------------------------------------------ 3. conv1 -> H1
   constexpr int Kp2 = HID, Kp3 = 9 * HID;    // both multiples of 64: no row padding
   constexpr int NCH = 4 / NS;                // channel tiles (32 channels) of conv2 per wave: tiles (nc0 + i) * 4 + wid
-  // W2 register ring: RD k-steps x NCH tiles.  32 fragments (128 VGPRs) beside the twelve accumulator tiles of a 96-pixel
-  // tile; tiles of 64 pixels or fewer (the deep levels, whose steps are bound by the latency of this very weight stream:
-  // one CU, ~1 us per round trip) leave room for 64 (256 VGPRs): twice the bytes in flight
-  constexpr int RFR = (MT32 <= 2 && NS == 1) ? 64 : 32;
-  constexpr int RD = RFR / NCH;
+  constexpr int RD = 32 / NCH;               // W2 register ring: RD k-steps x NCH tiles = 32 fragments (128 VGPRs)
   const int nc0 = qs * NCH;
   bf16x8f w2r[RD][NCH];
   const __amdgpu_buffer_rsrc_t r2 = f2_rsrc(F2S(sp, wf2), (unsigned)HID * Kp2 * 2);
@@ -449,8 +445,8 @@ __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   // and its epilogue (all 32 at once hold every wave at the vector-memory issue for ~2.5K cycles, the last wave longest)
   auto load_w2_part = [&](int part) {
 #pragma unroll
-    for (int e = 0; e < RFR / 4; ++e) {
-      const int f = part * (RFR / 4) + e;   // fragment f of the fill: k-step f / NCH of tile f % NCH
+    for (int e = 0; e < 8; ++e) {
+      const int f = part * 8 + e;   // fragment f of the fill: k-step f / NCH of tile f % NCH
       w2r[f / NCH][f % NCH] = f2_ldw(r2, voffL, w2s[f % NCH] + (f / NCH) * 1024);
     }
   };
