@@ -156,12 +156,12 @@ class Leg:
 
     def _build_runner(self, kind):
         a, data = self.args, self.data
-        if kind in ("ahead", "pipelined"):
+        if kind in ("ahead", "pipelined", "staged"):
             # software pipeline across steps: the frozen teacher's forward for batch t+1 runs on a side stream while the
             # student trains on batch t; every call still does one full step's work (nf_distillation_amd/pipeline.py).
             # "ahead": the teacher two batches ahead, its forward launched under the gradient all-reduce
-            from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep
-            cls = AheadPipelinedStep if kind == "ahead" else PipelinedStep
+            from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep, StagedPipelinedStep
+            cls = {"ahead": AheadPipelinedStep, "staged": StagedPipelinedStep}.get(kind, PipelinedStep)
             runner = cls(self.step, data[0], strict=True)
             if getattr(a, "phase_lock", None) is not None:
                 runner.phase_lock = bool(a.phase_lock)
@@ -189,7 +189,8 @@ class Leg:
         elif a.no_pipeline:
             order = ["graph", "eager"]
         else:
-            order = (["ahead"] if ahead else []) + ["pipelined", "graph", "eager"]
+            staged = a.teacher_stages == 2 or (a.teacher_stages is None and self.world == 1)
+            order = (["ahead"] if ahead else (["staged"] if staged else [])) + ["pipelined", "graph", "eager"]
         # one rank: a step that was not captured as asked is a failed run.  Several ranks (RCCL beside hipGraph capture has
         # never run in this repo's tests): degrade to the next simpler schedule and SAY so in config.schedule rather than
         # produce no number
@@ -205,7 +206,7 @@ class Leg:
                     raise SystemExit(4)
                 self.fallbacks.append(f"{kind}: {exc!r}"[:200])
                 torch.cuda.synchronize()
-        self.pipelined = self.kind in ("ahead", "pipelined")
+        self.pipelined = self.kind in ("ahead", "pipelined", "staged")
         if self.world == 1 and not a.no_graph and getattr(self.runner, "graph", None) is None:
             print("bench.py: the step was not captured into a hipGraph", file=sys.stderr)
             raise SystemExit(4)
@@ -213,7 +214,10 @@ class Leg:
     def schedule(self):
         """What is actually running, read from the runner (never from the flags)."""
         graph = getattr(self.runner, "graph", None) is not None
-        if graph and self.kind == "ahead":
+        if graph and self.kind == "staged":
+            s = ("hipGraph replay, software pipeline with the frozen teacher in two stages: teacher level 1 (t+2) || teacher deep "
+                 "levels (t+1) || student (t)")
+        elif graph and self.kind == "ahead":
             s = "hipGraph replay (three graphs), teacher two batches ahead: teacher(t+2) launched under all-reduce / optimiser (t)"
         elif graph and self.pipelined:
             s = "hipGraph replay, teacher(t+1) || student(t) software pipeline"
@@ -368,6 +372,9 @@ def main():
                     help="2: the teacher runs two batches ahead, its forward launched under the gradient all-reduce "
                          "(pipeline.AheadPipelinedStep).  Default: 2 for N > 1 (something overlaps the collective), 1 for "
                          "one GPU (no collective to hide; same speed)")
+    ap.add_argument("--teacher-stages", type=int, default=None, choices=(1, 2),
+                    help="2: the frozen teacher's forward as two pipeline stages beside each other (pipeline.StagedPipelinedStep: "
+                         "level 1 of batch t+2 || deeper levels of batch t+1 || student of batch t); default: 2 on one GPU")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="f32: the reference's precision (parity mode); bf16: bf16 operands / fp32 accumulate in the "

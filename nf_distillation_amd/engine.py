@@ -968,10 +968,11 @@ class _EncodeFn(torch.autograd.Function):
                 check(lib.nfk_step2d_fwd(C.byref(r.cs), ptr(cur), r.C, ptr(ld), ptr(zb), ptr(h1), ptr(h2), ptr(hs),
                                          ptr(ws), ptr(out), ptr(ld_out), s), "nfk_step2d_fwd")
                 ld = ld_out
-            elif (hints_only and r.idx not in keep and r.idx + 1 < len(st["recs"]) and st["recs"][r.idx + 1].kind == "squeeze"
-                  and cur is not None):
+            elif hints_only and r.idx not in keep and r.idx + 1 < len(st["recs"]) and st["recs"][r.idx + 1].kind == "squeeze":
                 # hints-only pass: Split2d passes z1 = the first half of the channels on; the squeeze that follows reads it in
                 # place, with the full rows' stride
+                if cur is None:
+                    cur = _nhwc(x)
                 out = cur[..., : r.C // 2]
                 cur_stride = r.C
                 saved.append(None)

@@ -429,3 +429,138 @@ class AheadPipelinedStep(PipelinedStep):
         cur.wait_stream(self.main)
         self.primed = False
         return [first, second]
+
+
+class StagedPipelinedStep(PipelinedStep):
+    """The software pipeline with the frozen teacher cut into TWO stages that run beside each other (and beside the student):
+
+        stage A   level 1 of the teacher on batch t+2         (32 launches that each want the whole chip)
+        stage B   the teacher's deeper levels on batch t+1    (two long launches on 64 CUs each: one per level)
+        student   forward / backward / optimiser on batch t
+
+    In `PipelinedStep` the teacher's forward is one chain of ~2 ms that has to fit beside the student's ~2.9 ms every call --
+    it is co-critical: shortening it by 70 us (the hints-only encode) shortened the step by 100 us.  Cut after level 1, its
+    longest stage is 1.1 ms and never on the critical path.  Every call still does one whole teacher forward's work (stage A
+    of one batch, stage B of another), one student forward + backward and one optimiser step, on the same values in the same
+    RNG order: parameters bit-identical to the sequential step (tests/test_gpu_pipeline.py).
+
+    Call pattern as `AheadPipelinedStep`: `prime(x0, x1)`, then `training_step(x_{t+2})` trains on batch t; `drain()` returns the
+    losses of the two batches still in flight.  The stages are two FlowEngines over slices of the teacher's layer list (shared,
+    frozen parameters; hints-only passes: engine.encode(..., keep, hints_only=True))."""
+
+    def __init__(self, step, example_x, use_graph=True, warmup=2, with_noise=False, strict=False):
+        super().__init__(step, example_x, use_graph, warmup, with_noise, strict)
+        from .engine import FlowEngine
+        from .modules import Split2d
+        layers = list(step.teacher.flow.layers)
+        cut = next((i for i, l in enumerate(layers) if isinstance(l, Split2d)), None)
+        if cut is None or getattr(step.teacher, "is_1d", False):
+            raise ValueError("the staged pipeline needs a multi-level image teacher")
+        self.cut = cut                                   # stage A = layers[:cut] (squeeze + level-1 steps), B = the rest
+        teng = step.teacher.flow.engine()
+        self.eng_a, self.eng_b = FlowEngine(layers[:cut]), FlowEngine(layers[cut:])
+        for e in (self.eng_a, self.eng_b):
+            e.set_compute_dtype("bf16" if teng.bf16 else "f32")
+            e.fused, e.fused_runs = teng.fused, teng.fused_runs
+        n = len(layers)
+        self.keep_a = [i for i in step.t_idx if i < cut]
+        self.keep_b = [(i % n) - cut for i in step.t_idx if (i % n) >= cut]
+        self.side_b = torch.cuda.Stream()
+        self.xs_a = torch.empty_like(example_x)          # student input of the batch stage A works on (age 0)
+        self.xs_b = torch.empty_like(example_x)          # ... of the batch stage B works on (age 1); x_cur is age 2
+        self.h_a = self.h_b = self.h_cur = None          # stage A's hint tensors at ages 0 / 1 / 2
+        self.za_a = self.za_cur = None                   # stage A's output: written (age 0) / read by stage B (age 1)
+        self.hb_a = self.hb_cur = None                   # stage B's hint tensors: written (age 1) / read by the student (age 2)
+        self.in_flight = 0
+
+    # ---- the two stages (each on the stream that is current when it is called)
+    def _stage_a(self):
+        st = self.step
+        n_s = self.ns_in if self.ns_in is not None else torch.empty_like(self.x_in).uniform_(0, 1.0 / 256)
+        self.x_in.add_(n_s)
+        self.xs_a.copy_(self.x_in)
+        n_t = self.nt_in if self.nt_in is not None else torch.empty_like(self.x_in).uniform_(0, 1.0 / 256)
+        self.eng_a.fused_split_inference = self.teacher_split
+        with torch.no_grad():
+            outs, _ = self.eng_a.encode(self.x_in, None, 0.0, n_t, keep=self.keep_a, hints_only=True)
+        hints, za = [outs[i] for i in self.keep_a], outs[-1]
+        if self.h_a is None:
+            self.h_a, self.h_b, self.h_cur = ([torch.empty_like(h) for h in hints] for _ in range(3))
+            self.za_a, self.za_cur = torch.empty_like(za), torch.empty_like(za)
+        torch._foreach_copy_(self.h_a + [self.za_a], hints + [za])
+
+    def _stage_b(self):
+        self.eng_b.fused_split_inference = self.teacher_split
+        with torch.no_grad():
+            outs, _ = self.eng_b.encode(self.za_cur, None, 0.0, None, keep=self.keep_b, hints_only=True)
+        hints = [outs[i] for i in self.keep_b]
+        if self.hb_a is None:
+            self.hb_a, self.hb_cur = [torch.empty_like(h) for h in hints], [torch.empty_like(h) for h in hints]
+        torch._foreach_copy_(self.hb_a, hints)
+
+    def _shift(self, full=True):
+        """Everything moves one age on: what the student reads first (two multi-tensor copies: the second one's sources are
+        the first one's destinations' sources)."""
+        if full:
+            torch._foreach_copy_(self.h_cur + self.hb_cur + [self.x_cur, self.za_cur], self.h_b + self.hb_a + [self.xs_b, self.za_a])
+            self.t_cur = self.h_cur + self.hb_cur
+        else:   # priming: no stage-B results yet
+            self.za_cur.copy_(self.za_a)
+        torch._foreach_copy_(self.h_b + [self.xs_b], self.h_a + [self.xs_a])
+
+    def _fork_stages(self, main, run_a=True, run_b=True):
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for stream, fn, on in ((self.side, self._stage_a, run_a), (self.side_b, self._stage_b, run_b)):
+            if not on:
+                continue
+            stream.wait_event(fork)
+            with torch.cuda.stream(stream):
+                fn()
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                joins.append(ev)
+        return joins
+
+    def _body_a(self):
+        main = torch.cuda.current_stream()
+        self._shift()
+        joins = self._fork_stages(main)
+        out = self._student_fwd_bwd()
+        for ev in joins:
+            main.wait_event(ev)
+        return out
+
+    # ---- public API
+    def prime(self, x0, x1=None, noise_s=None, noise_t=None, noise_s1=None, noise_t1=None):
+        x1 = x0 if x1 is None else x1
+        main = torch.cuda.current_stream()
+        self._load(x0, noise_s, noise_t)
+        self._stage_a()                                   # batch 0 through stage A
+        self._shift(full=False)
+        self._load(x1, noise_s1 if noise_s1 is not None else noise_s, noise_t1 if noise_t1 is not None else noise_t)
+        for ev in self._fork_stages(main):                # batch 1 through stage A beside batch 0 through stage B
+            main.wait_event(ev)
+        self.primed, self.in_flight = True, 2
+
+    def prepare(self, x0, noise_s=None, noise_t=None):
+        self.prime(x0, x0, noise_s, noise_t)
+        while self.use_graph and self.graph is None:
+            self.training_step(x0, noise_s, noise_t)
+
+    def drain(self):
+        """Train on the two batches still in flight (no new teacher input); returns the losses of both, oldest first."""
+        main = torch.cuda.current_stream()
+        outs = []
+        for left in (2, 1):
+            self._shift()
+            joins = self._fork_stages(main, run_a=False, run_b=left == 2)
+            out = self._student_fwd_bwd()
+            for ev in joins:
+                main.wait_event(ev)
+            self.step.allreduce()
+            self.step.optimize()
+            outs.append({k: v.clone() for k, v in out.items()})
+        self.primed = False
+        return outs
