@@ -143,6 +143,8 @@ class Leg:
         if args.level_backward is not None:   # experiment knob: 0 per-step calls, 1 per level / one launch per step, 2 + runs, 3 + aux
             e = self.student.flow.engine()
             e.level_backward, e.level_multi, e.level_wgrad_aux = args.level_backward >= 1, args.level_backward >= 2, args.level_backward >= 3
+        if args.wgrad_chunk is not None:
+            self.student.flow.engine().level_wgrad_chunk = args.wgrad_chunk
         self.step = DistillationStep(self.student, self.teacher, nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
         if not args.no_overlap:
             self.step.enable_concurrency()  # teacher fwd || student fwd, wgrad || dgrad on side streams
@@ -357,6 +359,7 @@ def main():
     ap.add_argument("--level-backward", type=int, default=None, choices=(0, 1, 2, 3),
                     help="experiment knob: the student's bf16 backward -- 0 per-step calls, 1 per level with one launch per step, "
                          "2 with runs of steps in one launch, 3 with the per-level launches on the auxiliary stream (default: the engine's)")
+    ap.add_argument("--wgrad-chunk", type=int, default=None, help="experiment knob: engine.level_wgrad_chunk of the student")
     ap.add_argument("--student-first", type=int, default=None, choices=(0, 1),
                     help="experiment knob: PipelinedStep.student_first (order in which the two branches' graph nodes are created)")
     ap.add_argument("--phase-lock", type=int, default=None, choices=(0, 1),

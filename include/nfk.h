@@ -317,6 +317,9 @@ typedef struct nfk_level_bwd {
   int32_t k_lo, k_hi;                            /* steps k_hi, k_hi - 1, ..., k_lo are walked (0 <= k_lo <= k_hi < nsteps) */
   int32_t multi;                                 /* 1: one launch for all of them where the geometry allows, 0: one per step */
   nfk_aux *aux;                                  /* optional: the two per-level launches go to this stream (join: nfk_aux_join) */
+  int32_t wgrad_chunk, pad_;                     /* > 0 (one launch per step only): the weight-gradient / reduction launches go out
+                                                  * for every `wgrad_chunk` steps walked instead of once per call -- on `aux` they
+                                                  * then run beside the remaining steps' launches */
 } nfk_level_bwd;
 int nfk_level_bwd_ok(const nfk_step2d *first);        /* 1: nfk_level2d_bwd covers this geometry */
 int nfk_level_bwd_parts(const nfk_step2d *first);     /* partial (gWf, gcf) slabs per step = workgroups of the step launch */

@@ -709,24 +709,34 @@ int nfk_level2d_bwd(const nfk_level_bwd* lv, const nfk_step2d* host_steps, void*
   fc.gz[0] = ws + L.gz0; fc.gz[1] = ws + L.gz1; fc.tailpart = ws + L.tailpart;
   fc.stamps = g_bwd_stamps;
   fc.ga = ws + L.ga; fc.ga_stride = (long)L.ga_stride; fc.o_ga2 = (long)L.o_ga2; fc.o_ga1 = (long)L.o_ga1; fc.o_x3 = (long)L.o_x3;
-  int grid = 0;
-  NFK_TRY(fusedb_level_launch(fc, st, &grid));
-  // 3. all weight-gradient GEMMs + ActNorm sums, then every reduction into the parameter gradients
-  hipStream_t wst = st;
   nfk_aux* const ax = lv->aux;
-  if (ax && ax->stream != st) { fork_to_aux(ax, st, 0); wst = ax->stream; }
   LevelWgradArgs wa{};
-  wa.steps = lv->steps; wa.grads = lv->grads; wa.k_lo = lv->k_lo; wa.k_hi = kh;
+  wa.steps = lv->steps; wa.grads = lv->grads;
   wa.B = B; wa.H = s->H; wa.W = s->W; wa.M = M; wa.hid = s->hidden; wa.Cout = Cout; wa.Ch = C / 2; wa.K3p = L.K3p; wa.K1p = L.K1p;
-  wa.S = level_wgrad_splits(M, s->hidden, L.K3p, L.K1p, kh - lv->k_lo + 1);
   wa.ga = ws + L.ga; wa.ga_stride = (long)L.ga_stride; wa.o_ga2 = (long)L.o_ga2; wa.o_ga1 = (long)L.o_ga1; wa.o_x3 = (long)L.o_x3;
   wa.h1 = lv->h1save; wa.h2 = lv->h2save; wa.h_stride = lv->h_stride;
   wa.masks = reinterpret_cast<const unsigned char*>(lv->masks); wa.mask_stride = lv->mask_stride;
   wa.o_x1 = (long)2 * M * (s->hidden / 8);
   wa.wslab = ws + L.wslab; wa.wslab_stride = (long)L.wslab_stride; wa.o_s2 = (long)L.o_s2; wa.o_s1 = (long)L.o_s1;
   wa.o_col2 = (long)L.o_col2; wa.o_col1 = (long)L.o_col1;
-  wa.tailpart = ws + L.tailpart; wa.rows_top = B * cb.tiles; wa.rows = grid;
-  return level_wgrad_launch(wa, wst, wst);
+  wa.tailpart = ws + L.tailpart; wa.rows_top = B * cb.tiles; wa.k_top = kh;
+  // steps in chunks: [the chunk's launches] then, on `aux` if there is one, its weight-gradient GEMMs + reductions -- which
+  // run beside the next chunk's launches.  One chunk = the whole walk unless the caller asks for less (a run of steps in
+  // one launch is always one chunk)
+  const bool run = lv->multi && kh > lv->k_lo && fusedb_level_multi_ok(*s);
+  const int chunk = (run || lv->wgrad_chunk <= 0) ? kh - lv->k_lo + 1 : lv->wgrad_chunk;
+  for (int hi = kh; hi >= lv->k_lo; hi -= chunk) {
+    const int lo = hi - chunk + 1 > lv->k_lo ? hi - chunk + 1 : lv->k_lo;
+    fc.run_hi = hi; fc.run_lo = lo;
+    int grid = 0;
+    NFK_TRY(fusedb_level_launch(fc, st, &grid));
+    hipStream_t wst = st;
+    if (ax && ax->stream != st) { fork_to_aux(ax, st, 0); wst = ax->stream; }
+    wa.k_lo = lo; wa.k_hi = hi; wa.rows = grid;
+    wa.S = level_wgrad_splits(M, s->hidden, L.K3p, L.K1p, hi - lo + 1);
+    NFK_TRY(level_wgrad_launch(wa, wst, wst));
+  }
+  return NFK_OK;
 }
 
 void nfk_debug_triple_parts(int skip_mask) { triple_wgrad_debug_skip(skip_mask); }

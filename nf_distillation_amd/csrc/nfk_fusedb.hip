@@ -985,6 +985,7 @@ static bool fb_level_pick(const nfk_step2d& s, FBArgs* a, FBGeom* gp, int* mo, i
   *gp = g; *mo = npx / 16; *grid = gr;
   return true;
 }
+int fusedb_level_multi_ok(const nfk_step2d& s) { return fusedb_level_ok(s) == 2; }
 int fusedb_level_ok(const nfk_step2d& s) {
   FBArgs a{};
   FBGeom g;
@@ -1027,15 +1028,17 @@ int fusedb_level_launch(const FusedLevelCall& c, hipStream_t st, int* grid_used)
   const int cls = NFK_PROF_FUSED_BWD + (M >= 8192 ? 0 : (M >= 2048 ? 1 : 2));
   const double fl = 2.0 * M * (512.0 * 9 * s.Cout + 512.0 * 512 + 9.0 * 512 * (s.C / 2));
   const double by = M * (4.0 * s.Cout + 4.0 * (s.C / 2) + 2 * 512 * 2.0 + 2 * 64.0) + 2.0 * 512 * (9.0 * s.Cout + 512 + 9.0 * (s.C / 2));
-  const int nwalk = c.lv.k_hi - c.lv.k_lo + 1;
+  const int nwalk = c.run_hi - c.run_lo + 1;
+  if (c.run_hi > c.lv.k_hi || c.run_lo < c.lv.k_lo || nwalk < 1) return NFK_ERR_ARG;
   if (c.lv.multi && a.halo == 0 && nwalk > 1) {
+    if (c.run_hi != c.lv.k_hi || c.run_lo != c.lv.k_lo) return NFK_ERR_ARG;   // a run is the whole walk
     a.k_hi = c.lv.k_hi; a.k_lo = c.lv.k_lo;
     prof_scope_begin(cls, nwalk * fl, nwalk * by, st);
     const int rc = fb_level_dispatch<true>(a, g, mo, grid, st);
     prof_scope_end(cls, st);
     return rc;
   }
-  for (int k = c.lv.k_hi; k >= c.lv.k_lo; --k) {
+  for (int k = c.run_hi; k >= c.run_lo; --k) {
     a.k_hi = a.k_lo = k;
     prof_scope_begin(cls, fl, by, st);
     const int rc = fb_level_dispatch<false>(a, g, mo, grid, st);

@@ -249,7 +249,7 @@ struct LevelWgradArgs {
   const void *h1, *h2; long h_stride;                      // bf16 elements
   const unsigned char* masks; long mask_stride, o_x1;      // bytes
   float* wslab; long wslab_stride, o_s2, o_s1, o_col2, o_col1;   // per step: slab3 | slab2 | slab1 | col2 | col1 (floats)
-  const float* tailpart; int rows_top, rows;               // [nsteps][256][2][Cout]; partial rows of step k_hi / the others
+  const float* tailpart; int rows_top, rows, k_top;        // [nsteps][256][2][Cout]; partial rows of step k_top / the others
 };
 int level_wgrad_tiles(int hid, int K3p, int K1p);
 int level_wgrad_splits(int M, int hid, int K3p, int K1p, int nwalk);
@@ -260,8 +260,10 @@ struct FusedLevelCall {
   nfk_step2d first;
   float* gz[2]; float* tailpart; float* ga; long ga_stride, o_ga2, o_ga1, o_x3;
   unsigned long long* stamps;   // diagnostic: [grid][16] cycle stamps of the last step of the last launch (null in production)
+  int run_hi, run_lo;           // the steps to launch now (a sub-range of lv.k_hi .. lv.k_lo, which define the walk)
 };
-int fusedb_level_ok(const nfk_step2d& s);      // 1: level mode covers this geometry; 2: also as ONE launch for all steps
+int fusedb_level_ok(const nfk_step2d& s);
+int fusedb_level_multi_ok(const nfk_step2d& s);      // 1: level mode covers this geometry; 2: also as ONE launch for all steps
 int fusedb_level_grid(const nfk_step2d& s);    // workgroups of a step launch (what the one-launch form uses may differ: see fusedb_level_launch)
 int fusedb_level_launch(const FusedLevelCall& c, hipStream_t st, int* grid_used);
 }  // namespace nfk

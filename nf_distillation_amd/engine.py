@@ -72,7 +72,12 @@ class FlowEngine:
         # (nfk_step2d_bwd_chain), which the level form is tested against
         self.level_backward = True
         self.level_multi = True
-        self.level_wgrad_aux = False     # the two per-level launches on the auxiliary stream (`aux`), joined once per backward
+        # the per-level launches on the auxiliary stream (`aux`, set by training.enable_concurrency; without one they stay on
+        # the caller's), joined once per backward: they then run beside the next level's step launches (+3 % of the step)
+        self.level_wgrad_aux = True
+        # ... and, where a level's steps are one launch each, go out for every `level_wgrad_chunk` steps instead of once per
+        # level (0): the last level's GEMMs would otherwise all sit behind its last step, at the end of the critical path
+        self.level_wgrad_chunk = 2
         self.bwd_mode = capi.BWD_DEFAULT   # nfk_step2d_grads.bwd_mode: how the bf16 backward of a coupling net is launched
         self.defer_fused_wgrad = False   # bf16 fused backward: weight-gradient launches as a chain of their own on `aux`
         self.aux = None        # nfk_aux handle (training.enable_concurrency): auxiliary stream of the weight-gradient GEMMs
@@ -1150,6 +1155,7 @@ class _EncodeFn(torch.autograd.Function):
             lv.g_ld, lv.ws = ptr(g_ld), wsc[first].data_ptr()
             lv.multi = 1 if eng.level_multi else 0
             lv.aux = eng.aux if (eng.level_wgrad_aux and eng.grad_hook is None) else None
+            lv.wgrad_chunk = int(eng.level_wgrad_chunk) if lv.aux else 0
             k_hi = n - 1
             while k_hi >= 0:
                 ext = _ext(i + (n - 1 - k_hi))
