@@ -75,9 +75,10 @@ class FlowEngine:
         # the per-level launches on the auxiliary stream (`aux`, set by training.enable_concurrency; without one they stay on
         # the caller's), joined once per backward: they then run beside the next level's step launches (+3 % of the step)
         self.level_wgrad_aux = True
-        # ... and, where a level's steps are one launch each, go out for every `level_wgrad_chunk` steps instead of once per
-        # level (0): the last level's GEMMs would otherwise all sit behind its last step, at the end of the critical path
-        self.level_wgrad_chunk = 2
+        # ... and, where a level's steps are one launch each, could go out for every `level_wgrad_chunk` steps instead of once
+        # per level (0).  Measured and left off: beside the level-1 step launches, which want the whole chip themselves, the
+        # chunks cost more than the shorter tail gains (CIFAR B=64: 20 330 images/s at 0, 20 040 / 19 620 / 18 670 at 4 / 2 / 1)
+        self.level_wgrad_chunk = 0
         self.bwd_mode = capi.BWD_DEFAULT   # nfk_step2d_grads.bwd_mode: how the bf16 backward of a coupling net is launched
         self.defer_fused_wgrad = False   # bf16 fused backward: weight-gradient launches as a chain of their own on `aux`
         self.aux = None        # nfk_aux handle (training.enable_concurrency): auxiliary stream of the weight-gradient GEMMs

@@ -83,8 +83,10 @@ def image_case(name, s_cfg, t_cfg, batch, dev, steps=20):
             "student_steps_on_fused_forward": f"{sum(fused_fwd)} of {len(fused_fwd)}"}
 
 
-def tab_case(d, K, hid, batch, dev):
+def tab_case(d, K, hid, batch, dev, made=False):
     cfg = glow_cfg([d], K, 1, hid, is_1d=True)
+    if made:
+        cfg["flow_coupling"] = "made"
     model = build(cfg, 31, dev, "f32")
     step = DistillationStep(model, None, nll_weight=1.0, kd_weight=0.0, lr=5e-4, clip_norm=30.0)
     x = torch.randn(batch, d, device=dev)
@@ -99,7 +101,8 @@ def tab_case(d, K, hid, batch, dev):
     dt_fwd = time_steps(fwd, steps, 5)
     bytes_fwd = K * 2 * batch * d * 4
     flop_row = K * (2 * ((d // 2) * hid + 4 * hid * hid + hid * 2 * (d - d // 2)) + 2 * d * d)
-    return {"config": f"1-D Glow d={d} K={K} h={hid}", "batch_rows": batch, "train_rows_per_s": batch / dt_train,
+    return {"config": (f"MAF / MADE blocks d={d} K={K} h={hid} (parity unpinned: no reference code)" if made
+                       else f"1-D Glow d={d} K={K} h={hid}"), "batch_rows": batch, "train_rows_per_s": batch / dt_train,
             "train_ms_per_step": 1e3 * dt_train, "train_schedule": "hipGraph replay (forward + backward + clip + Adam)",
             "forward_rows_per_s": batch / dt_fwd, "forward_ms": 1e3 * dt_fwd, "forward_schedule": "eager, K launches",
             "roofline_forward": {"bound": "hbm", "algorithmic_bytes": bytes_fwd, "achieved_GBps": bytes_fwd / dt_fwd / 1e9,
@@ -111,6 +114,10 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs.json"
     dev = torch.device("cuda", 0)
     rows = []
+    rows.append(image_case("CIFAR-10 Glow L=3 K=8 h=512, student-only training step, bf16 (BASELINE config 2)",
+                           glow_cfg([32, 32, 3], 8, 3, 512), None, 64, dev, steps=30))
+    print(rows[-1], flush=True)
+    torch.cuda.empty_cache()
     rows.append(image_case("CelebA-64 Glow L=4 K=32 h=512, training step (BASELINE config 4)", glow_cfg([64, 64, 3], 32, 4, 512),
                            None, 16, dev, steps=10))
     print(rows[-1], flush=True)
@@ -122,6 +129,8 @@ def main():
     for d, K in ((6, 5), (63, 10)):
         for batch in (1024, 65536):
             rows.append(tab_case(d, K, 32, batch, dev))
+            print(rows[-1], flush=True)
+            rows.append(tab_case(d, K, 32, batch, dev, made=True))
             print(rows[-1], flush=True)
     json.dump({"what": "1 x MI355X; see tools/config_bench.py", "rows": rows}, open(out, "w"), indent=1)
 
