@@ -32,7 +32,19 @@ def glow_cfg(shape, K, L, hid, is_1d=False):
 
 def build(cfg, seed, dev, dtype):
     m = nfa.create_glow_model(cfg)
-    m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), seed))
+    if cfg.get("flow_coupling") == "made":   # (MADE blocks: masks are buffers of the model; parameters as tests/test_gpu_made.py)
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for k, v in m.state_dict().items():
+            if ".mask" in k:
+                sd[k] = v.clone()
+            elif k.endswith("weight"):
+                sd[k] = torch.randn(v.shape, generator=g) * (0.6 / v.shape[1] ** 0.5)
+            else:
+                sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        m.load_state_dict(sd)
+    else:
+        m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), seed))
     return m.to(dev).set_compute_dtype(dtype)
 
 
