@@ -548,7 +548,15 @@ __global__ void tab_reduce_kernel(TabStep s, nfk_tab_grads g, const float* __res
   const int NP = tab_param_floats(s);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NP; i += gridDim.x * blockDim.x) {
     float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += part[(long)b * NP + i];
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {   // eight slabs' loads in flight (a plain loop is a chain of nblk round trips)
+      float u[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = part[(long)(b + e) * NP + i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t += u[e];
+    }
+    for (; b < nblk; ++b) t += part[(long)b * NP + i];
     int o = 0;
     for (int l = 0; l < 6; ++l) {
       const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l), n = no * (nin + 1);
@@ -562,7 +570,9 @@ __global__ void tab_reduce_kernel(TabStep s, nfk_tab_grads g, const float* __res
   }
 }
 
-constexpr int TAB_MAX_BLOCKS = 128;
+// backward: one workgroup per CU (its LDS holds the tile's activations AND the per-workgroup weight-gradient sums: ~125 KB at
+// d = 63), every one with a slab of partial sums of its own.  (128 until round 3: half the chip idle at 65 536 rows.)
+constexpr int TAB_MAX_BLOCKS = 256;
 
 static int tab_blocks(const TabStep& s, bool bwd) {
   const int nt = ceil_div(s.B, tab_rows(s.hid, s.d));
