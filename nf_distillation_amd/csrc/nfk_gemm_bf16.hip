@@ -8,6 +8,7 @@
 //   * accumulation, ActNorm scale/bias, ReLU, masks and per-channel sums stay fp32; narrow inputs
 //     (z1, g_a3: C <= 96 channels) stay fp32 in HBM and are converted while staging (XF32)
 #include "nfk_internal.h"
+#include <type_traits>
 #include "nfk_repack.h"
 #include "nfk_tail.h"
 
@@ -443,7 +444,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int c0, 
 // per-load index arithmetic of the general case -- two integer divisions per Q piece for the tap geometry, element-wise
 // fallbacks -- drops out at compile time (it sat in front of every chunk's loads: ~300 VALU instructions per chunk and thread
 // beside 512 cycles of MFMA).
-template <int TN, int TM, int WN, int WM, bool PLAIN = false>
+// PF: pixel chunks kept in flight in REGISTERS ahead of the one being stored to LDS.  1: a chunk is requested one iteration
+// before it is needed -- every iteration then costs most of a memory round trip (~2 k cycles) beside 512 cycles of MFMA, and
+// the GEMM is a latency-bound pipeline.  3 (the level launches, whose splits are long: 16-64 chunks per workgroup): requested
+// three iterations ahead, 96 VGPRs of staging.
+template <int TN, int TM, int WN, int WM, bool PLAIN = false, int PF = 1>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, const int S, const int z_in) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
   constexpr int SP = wg_stride(BI), SQ = wg_stride(BJ);
@@ -493,8 +498,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
 #pragma unroll
   for (int t = 0; t < QL; ++t) q_pl[t] = (tid + 256 * t) / QG;
 
-  u32x4b preg[PL], qreg[QL];
-  auto gload = [&](int chunk) {
+  u32x4b pregs[PF][PL], qregs[PF][QL];
+  auto gload = [&](int chunk, u32x4b (&preg)[PL], u32x4b (&qreg)[QL]) {
     const int mb = chunk * WPX;
 #pragma unroll
     for (int t = 0; t < PL; ++t) {
@@ -547,7 +552,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const u32x4b (&preg)[PL], const u32x4b (&qreg)[QL]) {
     char* Ps = smem_b + buf * STAGE;
     char* Qs = Ps + WPX * SP;
 #pragma unroll
@@ -567,14 +572,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (c_begin < c_end) {
-    gload(c_begin);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int c = c_begin; c < c_end; ++c) {
-    const int buf = (c - c_begin) & 1;
-    if (c + 1 < c_end) gload(c + 1);
+  auto compute = [&](int buf) {
     const char* Ps = smem_b + buf * STAGE;
     const char* Qs = Ps + WPX * SP;
 #pragma unroll
@@ -590,8 +588,43 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
         for (int tm = 0; tm < TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tn], fb[tm], acc[tn][tm], 0, 0, 0);
     }
-    if (c + 1 < c_end) lstore(buf ^ 1);
+  };
+  if (PF == 1) {
+    if (c_begin < c_end) {
+      gload(c_begin, pregs[0], qregs[0]);
+      lstore(0, pregs[0], qregs[0]);
+    }
     __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+      const int buf = (c - c_begin) & 1;
+      if (c + 1 < c_end) gload(c + 1, pregs[0], qregs[0]);
+      compute(buf);
+      if (c + 1 < c_end) lstore(buf ^ 1, pregs[0], qregs[0]);
+      __syncthreads();
+    }
+  } else {
+    // chunk c_begin + r starts in register slot r; iteration c (slot r = (c - c_begin) % PF): chunk c is in LDS buffer
+    // (c - c_begin) & 1 (stored one iteration ago, or by the prologue), so slot r is free for chunk c + PF; chunk c + 1
+    // goes from slot (r + 1) % PF to the other LDS buffer, which every wave left at the previous iteration's barrier
+#pragma unroll
+    for (int r = 0; r < PF; ++r)
+      if (c_begin + r < c_end) gload(c_begin + r, pregs[r], qregs[r]);
+    if (c_begin < c_end) lstore(0, pregs[0], qregs[0]);
+    __syncthreads();
+    auto iter = [&](int c, auto rr) {
+      constexpr int r = decltype(rr)::value, rn = (r + 1) % PF;
+      const int buf = (c - c_begin) & 1;
+      if (c + PF < c_end) gload(c + PF, pregs[r], qregs[r]);
+      compute(buf);
+      if (c + 1 < c_end) lstore(buf ^ 1, pregs[rn], qregs[rn]);
+      __syncthreads();
+    };
+    static_assert(PF == 1 || PF == 3, "register ring: unrolled by hand for three slots");
+    for (int c = c_begin; c < c_end; c += 3) {
+      iter(c, std::integral_constant<int, 0>{});
+      if (c + 1 < c_end) iter(c + 1, std::integral_constant<int, 1 % PF>{});
+      if (c + 2 < c_end) iter(c + 2, std::integral_constant<int, 2 % PF>{});
+    }
   }
   const int iq = (lane >> 4) * 4, jl = lane & 15;
   float* outp = a.out + (long)z * a.slab_stride;
@@ -1094,7 +1127,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     w.P = gablk + a.o_ga2; w.ldp = a.hid; w.NI = a.hid;
     w.Q = reinterpret_cast<const float*>(h1); w.ldq = a.hid; w.Cq = a.hid; w.J = a.hid;
     w.out = ws + a.o_s2; w.slab_stride = (long)a.hid * a.hid;
-    wgrad_bf16_body<4, 4, 2, 2, true>(w, b % a.nb2, a.S, b / a.nb2);
+    wgrad_bf16_body<4, 4, 2, 2, true, 3>(w, b % a.nb2, a.S, b / a.nb2);
     return;
   }
   b -= a.nb2 * a.S;
@@ -1102,7 +1135,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     w.P = gablk + a.o_x3; w.ldp = a.K3p; w.NI = a.K3p;
     w.Q = reinterpret_cast<const float*>(h2); w.ldq = a.hid; w.Cq = a.hid; w.J = a.hid;
     w.out = ws; w.slab_stride = (long)a.K3p * a.hid;
-    wgrad_bf16_body<4, 4, 2, 2, true>(w, b % a.nb3, a.S, b / a.nb3);
+    wgrad_bf16_body<4, 4, 2, 2, true, 3>(w, b % a.nb3, a.S, b / a.nb3);
     return;
   }
   b -= a.nb3 * a.S;
@@ -1110,7 +1143,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     w.P = gablk + a.o_ga1; w.ldp = a.hid; w.NI = a.hid;
     w.Q = reinterpret_cast<const float*>(a.masks + (long)k * a.mask_stride + a.o_x1); w.ldq = a.K1p; w.Cq = a.K1p; w.J = a.K1p;
     w.out = ws + a.o_s1; w.slab_stride = (long)a.hid * a.K1p;
-    wgrad_bf16_body<4, 4, 2, 2, true>(w, b % a.nb1, a.S, b / a.nb1);
+    wgrad_bf16_body<4, 4, 2, 2, true, 3>(w, b % a.nb1, a.S, b / a.nb1);
   }
 }
 
