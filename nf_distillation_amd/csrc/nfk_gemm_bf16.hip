@@ -444,10 +444,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int c0, 
 // per-load index arithmetic of the general case -- two integer divisions per Q piece for the tap geometry, element-wise
 // fallbacks -- drops out at compile time (it sat in front of every chunk's loads: ~300 VALU instructions per chunk and thread
 // beside 512 cycles of MFMA).
-// PF: pixel chunks kept in flight in REGISTERS ahead of the one being stored to LDS.  1: a chunk is requested one iteration
-// before it is needed -- every iteration then costs most of a memory round trip (~2 k cycles) beside 512 cycles of MFMA, and
-// the GEMM is a latency-bound pipeline.  3 (the level launches, whose splits are long: 16-64 chunks per workgroup): requested
-// three iterations ahead, 96 VGPRs of staging.
+// PF: pixel chunks kept in flight in REGISTERS ahead of the one being stored to LDS (1: requested one iteration before it is
+// needed; 3: three iterations ahead, 96 VGPRs of staging).  Round 3 measured 3 on the level launches (16-64 chunks per
+// workgroup): results identical, time identical (CIFAR level 1: 245 us for 90 GFLOP either way) -- with two workgroups per
+// CU the loads were hidden already; what bounds the body is the LDS: per 64-pixel chunk a wave reads 16 KB of transposed
+// fragments (ds_read_b64_tr_b16) for 512 cycles of MFMA, i.e. 128 B/clk per workgroup, the array's whole bandwidth, and two
+// workgroups share it.  Kept at 1.
+constexpr int LEVEL_WGRAD_PF = 1;
 template <int TN, int TM, int WN, int WM, bool PLAIN = false, int PF = 1>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, const int S, const int z_in) {
   constexpr int BI = 16 * TN * WN, BJ = 16 * TM * WM;
@@ -1127,7 +1130,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     w.P = gablk + a.o_ga2; w.ldp = a.hid; w.NI = a.hid;
     w.Q = reinterpret_cast<const float*>(h1); w.ldq = a.hid; w.Cq = a.hid; w.J = a.hid;
     w.out = ws + a.o_s2; w.slab_stride = (long)a.hid * a.hid;
-    wgrad_bf16_body<4, 4, 2, 2, true, 3>(w, b % a.nb2, a.S, b / a.nb2);
+    wgrad_bf16_body<4, 4, 2, 2, true, LEVEL_WGRAD_PF>(w, b % a.nb2, a.S, b / a.nb2);
     return;
   }
   b -= a.nb2 * a.S;
@@ -1135,7 +1138,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     w.P = gablk + a.o_x3; w.ldp = a.K3p; w.NI = a.K3p;
     w.Q = reinterpret_cast<const float*>(h2); w.ldq = a.hid; w.Cq = a.hid; w.J = a.hid;
     w.out = ws; w.slab_stride = (long)a.K3p * a.hid;
-    wgrad_bf16_body<4, 4, 2, 2, true, 3>(w, b % a.nb3, a.S, b / a.nb3);
+    wgrad_bf16_body<4, 4, 2, 2, true, LEVEL_WGRAD_PF>(w, b % a.nb3, a.S, b / a.nb3);
     return;
   }
   b -= a.nb3 * a.S;
@@ -1143,7 +1146,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     w.P = gablk + a.o_ga1; w.ldp = a.hid; w.NI = a.hid;
     w.Q = reinterpret_cast<const float*>(a.masks + (long)k * a.mask_stride + a.o_x1); w.ldq = a.K1p; w.Cq = a.K1p; w.J = a.K1p;
     w.out = ws + a.o_s1; w.slab_stride = (long)a.hid * a.K1p;
-    wgrad_bf16_body<4, 4, 2, 2, true, 3>(w, b % a.nb1, a.S, b / a.nb1);
+    wgrad_bf16_body<4, 4, 2, 2, true, LEVEL_WGRAD_PF>(w, b % a.nb1, a.S, b / a.nb1);
   }
 }
 
