@@ -663,7 +663,7 @@ LevelWs level_ws_layout(const nfk_step2d* s, int nsteps) {
   size_t o = 0;
   w.gz0 = o; o += align4(M * s->C);
   w.gz1 = o; o += align4(M * s->C);
-  w.tailpart = o; o += align4((size_t)nsteps * 256 * 2 * s->Cout);
+  w.tailpart = o; o += align4((size_t)nsteps * NFK_LEVEL_ROWS * 2 * s->Cout);
   w.ga = o; o += (size_t)nsteps * w.ga_stride;
   w.wslab = o; o += (size_t)nsteps * w.wslab_stride;
   w.total = o;
@@ -698,7 +698,7 @@ int nfk_level2d_bwd(const nfk_level_bwd* lv, const nfk_step2d* host_steps, void*
   cb.z = lv->zsave + (long)kh * lv->zsave_stride; cb.ldz = C; cb.h = lv->hsave + (long)kh * lv->hsave_stride;
   cb.es3 = host_steps[kh].es3; cb.ga3 = ws + L.ga + (size_t)kh * L.ga_stride;
   cb.gz = ws + ((kh & 1) ? L.gz1 : L.gz0); cb.ldgz = C;
-  cb.part = ws + L.tailpart + (size_t)kh * 256 * 2 * Cout;
+  cb.part = ws + L.tailpart + (size_t)kh * NFK_LEVEL_ROWS * 2 * Cout;
   cb.HW = HW; cb.C = C; cb.Cout = Cout; cb.additive = s->additive;
   cb.tiles = coupling_bwd_tiles(B, HW);
   if (B * cb.tiles > 256) return NFK_ERR_ARG;

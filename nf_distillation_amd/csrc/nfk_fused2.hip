@@ -129,7 +129,8 @@ __device__ __forceinline__ int f2_h1_off(int px, int slot) {
 template <int MT32, int NT3, int K1M, int NS, bool MULTI, int MO = 4>
 __global__ void __launch_bounds__(256) fused2_step_fwd_kernel(F2Args a) {
   static_assert(!MULTI || NS == 1, "a run of steps has no hidden split");
-  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MULTI && MT32 == 1), "small tiles: runs of steps on whole tiny images only");
+  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MULTI && MT32 == 1) || (MO == 2 && MT32 == 3 && !MULTI && NS == 1),
+                "small tiles: runs of steps on whole tiny images, or ONE 32-pixel image row (+ a halo row each side) per tile");
   constexpr int NPX = 16 * MO;   // output pixels of a tile
   typedef const __attribute__((address_space(4))) nfk_step2d CStep;   // scalar (constant-memory) loads of a descriptor
 #define F2S(p, f) (MULTI ? (p)->f : a.c.s.f)
@@ -788,10 +789,17 @@ static bool f2_pick(const nfk_step2d& s, F2Args* a) {
   if (lw < 1 || lh < 0) return false;   // W even: the channel mix takes pixels in pairs of one row
   const int HW = s.H * s.W;
   if (HW <= 64) { a->R = s.H; a->TS = 64 / HW; a->halo = 0; }
-  else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) { a->R = 64 / s.W; a->TS = 1; a->halo = 1; }
+  else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) {
+    a->R = 64 / s.W; a->TS = 1; a->halo = 1;
+    // rows of 32 pixels (CelebA-64 level 1): two rows + halo would be 128 pixels of h-region (16 accumulator tiles per
+    // wave in conv2: no room); ONE row per tile instead -- 32 output pixels, 96 computed (three times the conv1 / conv2
+    // work per output pixel instead of 1.5 times: still several times the per-conv launches' speed)
+    if (a->R == 2 && s.W == 32 && f2_geom(s, 2, 1, 1).MT32 > 3) a->R = 1;
+  }
   else return false;
   const F2Geom g = f2_geom(s, a->R, a->TS, a->halo);
   if (g.MT32 != 2 && g.MT32 != 3) return false;
+  if (a->TS == 1 && a->R * s.W != 64 && !(a->R * s.W == 32 && g.MT32 == 3)) return false;   // output pixels per tile: 64, or 32 (MO = 2)
   if (g.K1 > 256 || g.K1M * 16 != (g.K1 + 63) / 64 * 64) return false;   // wf1's k extent must be K1M k-steps
   if (g.total > 160 * 1024 - 512) return false;
   if ((size_t)4 * 64 * g.NT3 * 16 * 4 > (size_t)g.MT32 * 32 * 1024) return false;   // R3 lives in the h1 region
@@ -819,10 +827,11 @@ static int f2_launch_t(const F2Args& a, const F2Geom& g, int grid, hipStream_t s
   return NFK_OK;
 }
 
-template <int MT32, int NS, bool MULTI = false>
+template <int MT32, int NS, bool MULTI = false, int MO = 4>
 static int f2_dispatch(const F2Args& a, const F2Geom& g, int grid, hipStream_t st) {
   // instantiated for the shapes Glow produces: conv3 width grows with conv1's K (both follow C)
-  if (g.NT3 == 1 && g.K1M == 4) return f2_launch_t<MT32, 1, 4, NS, MULTI>(a, g, grid, st);
+  if (g.NT3 == 1 && g.K1M == 4) return f2_launch_t<MT32, 1, 4, NS, MULTI, MO>(a, g, grid, st);
+  if (MO != 4) return NFK_ERR_ARG;   // (32-pixel rows: level 1 only, C = 12)
   if (g.NT3 == 2 && g.K1M == 8) return f2_launch_t<MT32, 2, 8, NS, MULTI>(a, g, grid, st);
   if (g.NT3 == 3 && g.K1M == 16) return f2_launch_t<MT32, 3, 16, NS, MULTI>(a, g, grid, st);
   return NFK_ERR_ARG;
@@ -844,6 +853,7 @@ int fused2_tiles(const nfk_step2d& s) {
   const F2Geom g = f2_geom(s, a.R, a.TS, a.halo);
   const bool inst = (g.NT3 == 1 && g.K1M == 4) || (g.NT3 == 2 && g.K1M == 8) || (g.NT3 == 3 && g.K1M == 16);
   if (!inst) return 0;
+  if (a.TS == 1 && a.R * s.W == 32 && !(g.NT3 == 1 && g.K1M == 4)) return 0;   // 32-pixel tiles: the C = 12 shape only
   return a.TS == 1 ? s.H / a.R : 1;
 }
 
@@ -863,7 +873,10 @@ int fused2_launch(const FusedCall& c, hipStream_t st) {
   const F2Geom g = f2_geom(c.s, a.R, a.TS, a.halo);
   const int grid = f2_grid(c.s, a);
   const int ns = c.ws ? f2_splits(c.s, a, g, c.split_ways) : 1;   // ws == NULL: the caller does not want the hidden split
-  if (ns == 1) return g.MT32 == 2 ? f2_dispatch<2, 1>(a, g, grid, st) : f2_dispatch<3, 1>(a, g, grid, st);
+  if (ns == 1) {
+    if (a.TS == 1 && a.R * c.s.W == 32) return f2_dispatch<3, 1, false, 2>(a, g, grid, st);   // one 32-pixel row per tile
+    return g.MT32 == 2 ? f2_dispatch<2, 1>(a, g, grid, st) : f2_dispatch<3, 1>(a, g, grid, st);
+  }
   // hidden split: the step's mixed z must be kept (the coupling tail reads it), and the tail is a second launch
   if (!c.zsave) return NFK_ERR_ARG;
   { const int rc = ns == 2 ? f2_dispatch<2, 2>(a, g, grid, st) : f2_dispatch<2, 4>(a, g, grid, st); if (rc != NFK_OK) return rc; }

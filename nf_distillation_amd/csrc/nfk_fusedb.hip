@@ -41,7 +41,7 @@ struct FBArgs {
   nfk_level_bwd lv;
   int k_hi, k_lo;
   float* gz[2];          // [M][C] rows of dL/dz (mixed tensor), step k in gz[k & 1]: written by the coupling backward
-  float* tailpart;       // [nsteps][256][2][Cout] partial (sum g_a3, 3 sum g_h h) rows of the coupling backward
+  float* tailpart;       // [nsteps][NFK_LEVEL_ROWS][2][Cout] partial (sum g_a3, 3 sum g_h h) rows of the coupling backward
   float* ga;             // per-step blocks of ga_stride floats: g_a3 fp32 | g_a2 bf16 | g_a1 bf16 | dgrad3's im2col rows bf16
   long ga_stride, o_ga2, o_ga1, o_x3;   // (offsets in floats)
 };
@@ -116,7 +116,8 @@ __device__ __forceinline__ int fb_img_off(int px, int slot) {
 // The arithmetic per element is that of chanmix_body / coupling_bwd_kernel (nfk_tail.h, nfk_flow.hip).
 template <int MT32, int NTD, int K3M, int MO = 4, bool LV = false, bool MULTI = false>
 __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
-  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MT32 == 1), "small tiles: whole tiny images only");
+  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MT32 == 1) || (MO == 2 && MT32 == 3 && !MULTI),
+                "small tiles: whole tiny images, or one 32-pixel image row (+ halo rows) per tile");
   static_assert(!MULTI || LV, "runs of steps exist in level mode only");
   typedef const __attribute__((address_space(4))) nfk_step2d CStep;        // scalar (constant-memory) loads
   typedef const __attribute__((address_space(4))) nfk_level_grads CGrads;
@@ -841,7 +842,7 @@ __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
         }
       }
       // one partial row per workgroup: (sum g_a3, 3 sum g_h h), groups added in fixed order
-      float* prow = a.tailpart + ((long)(k - 1) * 256 + blockIdx.x) * 2 * Cout;
+      float* prow = a.tailpart + ((long)(k - 1) * NFK_LEVEL_ROWS + blockIdx.x) * 2 * Cout;
       for (int jj = tq; jj < C2n; jj += 256) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll 4
@@ -877,10 +878,15 @@ static bool fb_pick(const nfk_step2d& s, FBArgs* a) {
   if (lw < 0 || lh < 0) return false;
   const int HW = s.H * s.W;
   if (HW <= 64) { a->R = s.H; a->TS = 64 / HW; a->halo = 0; }
-  else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) { a->R = 64 / s.W; a->TS = 1; a->halo = 1; }
+  else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) {
+    a->R = 64 / s.W; a->TS = 1; a->halo = 1;
+    if (a->R == 2 && s.W == 32 && fb_geom(s, 2, 1, 1).MT32 > 3) a->R = 1;   // rows of 32 pixels: one row per tile (nfk_fused2.hip)
+  }
   else return false;
   const FBGeom g = fb_geom(s, a->R, a->TS, a->halo);
   if (g.MT32 != 2 && g.MT32 != 3) return false;
+  const bool row32 = a->TS == 1 && a->R * s.W == 32;
+  if (a->TS == 1 && a->R * s.W != 64 && !(row32 && g.MT32 == 3 && g.NTD == 1 && g.K3M == 8)) return false;
   if (g.total > 160 * 1024 - 512) return false;
   if ((size_t)4 * 64 * g.NTD * 16 * 4 > (size_t)g.MT32 * 32 * 1024) return false;   // R3 lives in the image
   if (a->TS * g.RZ * s.W * s.Cout > 12 * 256) return false;                          // prologue register slots
@@ -948,7 +954,8 @@ int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
       return rc;
     }
   }
-  if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<3, 1, 8>(a, g, grid, st);
+  if (a.TS == 1 && a.R * s.W == 32) rc = fb_launch_t<3, 1, 8, 2>(a, g, grid, st);
+  else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<3, 1, 8>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) rc = fb_launch_t<3, 1, 4>(a, g, grid, st);
   else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<2, 1, 8>(a, g, grid, st);
   else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) rc = fb_launch_t<2, 1, 16>(a, g, grid, st);
@@ -964,7 +971,7 @@ int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
 static bool fb_level_pick(const nfk_step2d& s, FBArgs* a, FBGeom* gp, int* mo, int* grid) {
   if (!fb_pick(s, a) || s.B > 256) return false;
   FBGeom g = fb_geom_lv(s, a->R, a->TS, a->halo);
-  int npx = 64, gr = a->TS == 1 ? s.B * (s.H / a->R) : (s.B + a->TS - 1) / a->TS;
+  int npx = (a->TS == 1) ? a->R * s.W : 64, gr = a->TS == 1 ? s.B * (s.H / a->R) : (s.B + a->TS - 1) / a->TS;
   const int HW = s.H * s.W;
   if (g_small_tiles && HW == 16 && a->halo == 0 && gr < 64 && g.NTD == 2 && g.K3M == 28) {
     FBArgs h = *a;
@@ -978,7 +985,7 @@ static bool fb_level_pick(const nfk_step2d& s, FBArgs* a, FBGeom* gp, int* mo, i
     }
   }
   const int C = s.C, C2 = C - C / 2;
-  if (g.total > 160 * 1024 - 512 || gr > 256 || gr < 1) return false;
+  if (g.total > 160 * 1024 - 512 || gr > NFK_LEVEL_ROWS || gr < 1) return false;
   if (fb_epi_floats(C, npx) * 4 > (size_t)g.MT32 * 32 * g.X3S) return false;    // the epilogue's scratch: the im2col region
   if (npx * C > 12 * 256 || C * C > 9 * 256 || C2 < 1 || C2 > 256) return false;   // its register slots
   if ((npx + 256 / C2 - 1) / (256 / C2) > 8) return false;                        // pixels per thread of the coupling backward
@@ -1003,6 +1010,7 @@ template <bool MULTI>
 static int fb_level_dispatch(const FBArgs& a, const FBGeom& g, int mo, int grid, hipStream_t st) {
   if (mo == 1 && g.MT32 == 1 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<1, 2, 28, 1, true, MULTI>(a, g, grid, st);
   if (mo == 2 && g.MT32 == 1 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<1, 2, 28, 2, true, MULTI>(a, g, grid, st);
+  if (mo == 2 && g.MT32 == 3 && g.NTD == 1 && g.K3M == 8 && !MULTI) return fb_launch_t<3, 1, 8, 2, true, false>(a, g, grid, st);
   if (mo != 4) return NFK_ERR_ARG;
   if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) return fb_launch_t<2, 1, 8, 4, true, MULTI>(a, g, grid, st);
   if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) return fb_launch_t<2, 1, 16, 4, true, MULTI>(a, g, grid, st);

@@ -1156,7 +1156,7 @@ __global__ void __launch_bounds__(256) level_tail_kernel(LevelWgradArgs a, const
   const nfk_level_grads g = a.grads[k];
   SmallGradArgs sg{};
   sg.col1 = ws + a.o_col1; sg.col2 = ws + a.o_col2; sg.mb1 = sg.mb2 = a.nparts; sg.n1 = sg.n2 = a.hid;
-  sg.tail = a.tailpart + (long)k * 256 * 2 * a.Cout; sg.B = (k == a.k_top) ? a.rows_top : a.rows; sg.n3 = a.Cout;
+  sg.tail = a.tailpart + (long)k * NFK_LEVEL_ROWS * 2 * a.Cout; sg.B = (k == a.k_top) ? a.rows_top : a.rows; sg.n3 = a.Cout;
   sg.g_l1 = g.g_l1; sg.g_b1 = g.g_b1; sg.g_l2 = g.g_l2; sg.g_b2 = g.g_b2; sg.g_bias3 = g.g_bias3; sg.g_l3 = g.g_l3;
   step_tail_body<true>(sg, f, blk, ws, ws + a.o_s2, ws + a.o_s1, g.g_w3, g.g_w2, g.g_w1);
 }

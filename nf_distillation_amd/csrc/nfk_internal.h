@@ -240,6 +240,7 @@ int wgrad_tail_bf16(WgradArgs w3, int S3, WgradArgs w2, int S2, WgradArgs w1, in
 
 // ---- level mode (nfk_level2d_bwd) ----
 constexpr int NFK_LEVEL_MAX_SPLITS = 4;
+constexpr int NFK_LEVEL_ROWS = 1024;   // partial rows / slabs a step of a level may leave (= workgroups of its launch)
 struct LevelWgradArgs {
   const nfk_step2d* steps; const nfk_level_grads* grads;   // device arrays
   int k_lo, k_hi;                                          // steps walked
@@ -249,7 +250,7 @@ struct LevelWgradArgs {
   const void *h1, *h2; long h_stride;                      // bf16 elements
   const unsigned char* masks; long mask_stride, o_x1;      // bytes
   float* wslab; long wslab_stride, o_s2, o_s1, o_col2, o_col1;   // per step: slab3 | slab2 | slab1 | col2 | col1 (floats)
-  const float* tailpart; int rows_top, rows, k_top;        // [nsteps][256][2][Cout]; partial rows of step k_top / the others
+  const float* tailpart; int rows_top, rows, k_top;        // [nsteps][NFK_LEVEL_ROWS][2][Cout]; partial rows of step k_top / the others
 };
 int level_wgrad_tiles(int hid, int K3p, int K1p);
 int level_wgrad_splits(int M, int hid, int K3p, int K1p, int nwalk);

@@ -208,6 +208,45 @@ def test_fused_step_variants(variant):
     assert float((bpd16 - bpd32).abs().max()) < 0.01, (bpd16, bpd32)
 
 
+def test_fused_step_on_32_pixel_rows():
+    """CelebA-64 geometry: level 1 is 32 x 32 (rows of 32 pixels): one image row (+ a halo row each side) per workgroup --
+    32 output pixels, 96 computed -- through the one-launch forward, the fused backward per level (and the per-step calls)
+    against the five-kernel bf16 path, as the CIFAR geometries above; bits/dim against fp32 parity mode (0.01)."""
+    import nf_distillation_amd as nfa
+    from nf_distillation_amd import capi
+    import ctypes
+    cfg = {"image_shape": [64, 64, 3], "hidden_channels": 512, "K": 2, "L": 2, "actnorm_scale": 1.0, "y_classes": 10,
+           "learn_top": False, "y_condition": False, "is_1d": False, "flow_coupling": "affine", "flow_permutation": "invconv",
+           "LU_decomposed": True}
+    sd = _random_parameters(cfg, 21)
+    x, noise = synthetic_images(3, (3, 64, 64), seed=64)
+    _compare_fused_unfused(cfg, sd, x, noise, seed=77)
+    model = build(cfg, sd, 77)
+    outs, bpd16, _ = model(x.clone().cuda(), None, noise=noise.cuda())
+    steps = [r for r in model.flow.engine().state["recs"] if r.kind == "step"]
+    assert all(capi.lib().nfk_step2d_fused_tiles(ctypes.byref(r.cs)) > 0 for r in steps)          # level 1 included
+    assert all(capi.lib().nfk_step2d_fused_bwd_ok(ctypes.byref(r.cs)) for r in steps)
+    assert capi.lib().nfk_step2d_fused_tiles(ctypes.byref(steps[0].cs)) == 32                       # one tile per image row
+    # the level form of the backward against the per-step calls on this geometry
+    grads = {}
+    for lvl in (True, False):
+        m = build(cfg, sd, 77)
+        m.flow.engine().level_backward = lvl
+        _, bpd, _ = m(x.clone().cuda(), None, noise=noise.cuda())
+        bpd.mean().backward()
+        torch.cuda.synchronize()
+        grads[lvl] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k, v in grads[False].items():
+        if float(v.abs().max()) > 0:
+            assert rel_err(grads[True][k], v) < 2e-5, (k, rel_err(grads[True][k], v))
+    torch.manual_seed(77)
+    m32 = nfa.create_glow_model(dict(cfg))
+    m32.load_state_dict({k: t.clone() for k, t in sd.items()})
+    with torch.no_grad():
+        _, bpd32, _ = m32.cuda()(x.clone().cuda(), None, noise=noise.cuda())
+    assert float((bpd16.detach() - bpd32).abs().max()) < 0.01, (bpd16, bpd32)
+
+
 def _grads_with(mode, halo, g, cfg, sd, x, noise, chain=False):
     """mode: 0 separate launches, 1 dual launches for small steps, 2 dual launches (nfk_step2d_grads.bwd_mode - 1)"""
     from nf_distillation_amd import capi
