@@ -25,7 +25,7 @@ Extra objects on the line (rank 0, N=1 only):
                     running the same step on the host cores for a bounded number of steps.
   oracle_check    : THIS geometry against the oracle (tests/oracle_check.py): the cpu_baseline leg's warm-up step (B=64,
                     parameters of seeds 11 / 12, batch seed 100) is also run through the HIP path on the same batch and
-                    noise -- default schedule (pipelined hipGraph) in both precisions, eager step in the headline one --
+                    noise -- default schedule (staged pipeline, one hipGraph) in both precisions, eager step in the headline one --
                     and step-0 nll / kd / loss / gradient norm / 64 sampled entries of every parameter gradient are
                     compared; the run FAILS (exit 5) on a miss.
   reference_precision_value / _ms_per_step : the f32 leg's numbers again, at top level (the reference computes in fp32;
@@ -54,7 +54,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec)
 GFLOP_PER_IMAGE = 14.04  # teacher fwd (8.023) + 3 x student fwd (2.006) per distillation step
-PMC_PROFILE = "r02_f_pmc_traffic_bf16.json"   # profiles/: FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
+PMC_PROFILE = "r03_a_pmc_traffic_bf16.json"   # profiles/: FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
 
 
 def cifar_cfg(K):
@@ -109,9 +109,9 @@ def cpu_baseline(batch, steps, want_digest=False):
 def oracle_check(digest, batch, headline_dtype, both):
     """HIP step vs the oracle's step on the same batch / noise / parameters (tests/oracle_check.py)."""
     import oracle_check as OC
-    cases = [(headline_dtype, "pipelined_graph"), (headline_dtype, "eager")]
+    cases = [(headline_dtype, "staged_graph"), (headline_dtype, "eager")]
     if both:
-        cases.append(("f32" if headline_dtype == "bf16" else "bf16", "pipelined_graph"))
+        cases.append(("f32" if headline_dtype == "bf16" else "bf16", "staged_graph"))
     block = {"sample": f"step 0 of the cpu_baseline leg: B={batch}, parameters of seeds {OC.SEED_STUDENT} / {OC.SEED_TEACHER}, "
                        "batch seed 100, same dequantisation noise", "bars": OC.BARS,
              "oracle": {k: digest[k] for k in ("nll", "kd", "result_loss", "grad_norm")}, "cases": {}}

@@ -251,8 +251,11 @@ PROF_CLASSES = ("conv_gemm_kernel<4,4,2,2> (128x128)", "conv_gemm_kernel<2,2,2,2
                           for conv in ("conv3 (block.4: wide dgrad + narrow wgrad)", "conv2 (block.2: 512x512)",
                                        "conv1 (block.0: narrow dgrad + wide wgrad)")
                           for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)")) \
-    + tuple(f"{k}, {lvl}" for k in ("fusedb_step_bwd_kernel (FlowStep backward: dgrad3 -> dgrad2 -> dgrad1 in one launch)",
-                                    "wgrad_tail_kernel (the step's three weight-gradient GEMMs + channel mix + the previous step's slab reductions in one launch)")
+    + tuple(f"{k}, {lvl}" for k in ("fusedb_step_bwd_kernel (FlowStep backward: dgrad3 -> dgrad2 -> dgrad1 [-> channel mix -> coupling "
+                                    "backward of the step below, level mode] in one launch; a run of steps in one launch: flops and "
+                                    "bytes of the whole run)",
+                                    "level_wgrad_kernel / wgrad_tail_kernel (weight-gradient GEMMs: all steps of a level in one launch "
+                                    "[level mode], or one step's three + channel mix + the previous step's reductions)")
             for lvl in ("M>=8192 (CIFAR level 1)", "M>=2048 (level 2)", "M<2048 (level 3)"))
 
 
@@ -261,9 +264,10 @@ PROF_SYMBOLS = {
     PROF_CLASSES[5]: "nfk::fused2_step_fwd_kernel<3, 1, 4, 1, false, 4>",
     PROF_CLASSES[6]: "nfk::fused2_step_fwd_kernel<2, 2, 8, 1, true, 4>",
     PROF_CLASSES[7]: "nfk::fused2_step_fwd_kernel<1, 3, 16, 1, true, 1>",
-    PROF_CLASSES[17]: "nfk::fusedb_step_bwd_kernel<3, 1, 8, 4>",
-    PROF_CLASSES[18]: "nfk::fusedb_step_bwd_kernel<2, 1, 16, 4>",
-    PROF_CLASSES[19]: "nfk::fusedb_step_bwd_kernel<1, 2, 28, 1>",
+    PROF_CLASSES[17]: "nfk::fusedb_step_bwd_kernel<3, 1, 8, 4, true, false>",
+    PROF_CLASSES[18]: "nfk::fusedb_step_bwd_kernel<2, 1, 16, 4, true, true>",
+    PROF_CLASSES[19]: "nfk::fusedb_step_bwd_kernel<1, 2, 28, 1, true, true>",
+    PROF_CLASSES[20]: "nfk::level_wgrad_kernel",
 }
 
 

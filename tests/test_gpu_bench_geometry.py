@@ -1,5 +1,5 @@
 """The geometry bench.py times (CIFAR pair, B=64, parameters of seeds 11 / 12) against the oracle, step 0, both
-precisions, through the eager step and through the default schedule (pipelined hipGraph).  At B=64 the engine picks code
+precisions, through the eager step and through the default schedule (staged pipeline in one hipGraph; round 2's as well).  At B=64 the engine picks code
 paths no smaller fixture reaches (level 1 as 256 unsplit workgroups, level 3 on 16-pixel tiles, weight-gradient split
 caps, the pipelined schedule's split policy): this is where they meet the reference's arithmetic.  Bars: tests/oracle_check.py."""
 import pytest
@@ -16,8 +16,8 @@ def oracle_ref():
     return OC.oracle_step(BATCH)
 
 
-@pytest.mark.parametrize("dtype,schedule", [("f32", "eager"), ("f32", "pipelined_graph"), ("bf16", "eager"),
-                                            ("bf16", "pipelined_graph")])
+@pytest.mark.parametrize("dtype,schedule", [("f32", "eager"), ("f32", "staged_graph"), ("bf16", "eager"),
+                                            ("bf16", "staged_graph"), ("bf16", "pipelined_graph")])
 def test_bench_geometry_step_matches_oracle(oracle_ref, dtype, schedule):
     scal, grads, _ = OC.hip_step(dtype, schedule, BATCH)
     res = OC.compare(oracle_ref, scal, grads, dtype)

@@ -1,10 +1,10 @@
-# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>      e.g. r02_a
+# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>      e.g. r03_a
 # Writes under gpurun_out/: the default bench line, the rocprofv3 kernel stats of the same command (+ its bench line), the
 # two HBM-traffic PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace only) summarised by tools/pmc_traffic.py,
 # and the MFMA-busy pass (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS..., GRBM_GUI_ACTIVE) summarised by tools/pmc_mfma.py.
 # The program itself follows `--` (never env / bash -c: the profiler has initialised the GPU by then).
 set -e
-tag=${1:-r02_x}
+tag=${1:-r03_x}
 out=gpurun_out
 export TMPDIR=/tmp
 python3 bench.py > $out/${tag}_bench_bf16.json 2> $out/${tag}_bench.err
