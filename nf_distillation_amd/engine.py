@@ -13,6 +13,7 @@ gradients straight into ``param.grad`` (pre-allocated, e.g. views of one flat bu
 see training.FlatParams), so no per-parameter autograd bookkeeping runs on the hot path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -74,7 +75,7 @@ class FlowEngine:
         self.level_multi = True
         # the per-level launches on the auxiliary stream (`aux`, set by training.enable_concurrency; without one they stay on
         # the caller's), joined once per backward: they then run beside the next level's step launches (+3 % of the step)
-        self.level_wgrad_aux = True
+        self.level_wgrad_aux = os.environ.get("NFK_LEVEL_WGRAD_AUX", "1") != "0"   # (environment knob: diagnostics)
         # ... and, where a level's steps are one launch each, could go out for every `level_wgrad_chunk` steps instead of once
         # per level (0).  Measured and left off: beside the level-1 step launches, which want the whole chip themselves, the
         # chunks cost more than the shorter tail gains (CIFAR B=64: 20 330 images/s at 0, 20 040 / 19 620 / 18 670 at 4 / 2 / 1)
