@@ -898,6 +898,7 @@ static bool fb_pick(const nfk_step2d& s, FBArgs* a) {
   if (a->lhw < 0) a->lhw = 0;
   // instantiated for the shapes Glow produces
   return (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) || (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) ||
+         (g.MT32 == 3 && g.NTD == 1 && g.K3M == 16) ||   // 16 x 16 x 24: level 2 of 64 x 64 images
          (g.MT32 == 2 && g.NTD == 2 && g.K3M == 28) || (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) ||
          (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4);
 }
@@ -956,6 +957,7 @@ int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
   }
   if (a.TS == 1 && a.R * s.W == 32) rc = fb_launch_t<3, 1, 8, 2>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<3, 1, 8>(a, g, grid, st);
+  else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 16) rc = fb_launch_t<3, 1, 16>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) rc = fb_launch_t<3, 1, 4>(a, g, grid, st);
   else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<2, 1, 8>(a, g, grid, st);
   else if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) rc = fb_launch_t<2, 1, 16>(a, g, grid, st);
@@ -1017,6 +1019,7 @@ static int fb_level_dispatch(const FBArgs& a, const FBGeom& g, int mo, int grid,
   if (g.MT32 == 2 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<2, 2, 28, 4, true, MULTI>(a, g, grid, st);
   if (MULTI) return NFK_ERR_ARG;   // tiles with halo rows: one launch per step
   if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) return fb_launch_t<3, 1, 8, 4, true, false>(a, g, grid, st);
+  if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 16) return fb_launch_t<3, 1, 16, 4, true, false>(a, g, grid, st);
   if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) return fb_launch_t<3, 1, 4, 4, true, false>(a, g, grid, st);
   return NFK_ERR_ARG;
 }
