@@ -84,7 +84,10 @@ int splitk_of(int bf16, int M, int N, int K) {
 // two engines on two threads / streams do not share any state.
 struct nfk_aux {
   hipStream_t stream;
-  hipEvent_t ev[4];
+  hipEvent_t ev[4];       // per-call forks of the per-step paths (0..2) and the join (3)
+  hipEvent_t lev[16];     // forks of the level backward: a different event for every fork of a backward pass (round 3: with ONE
+  int lev_next;           // event re-recorded for each level, a hipGraph that also held a side-stream branch crashed in
+                          // hipGraphLaunch -- only in a process that had captured other aux-stream graphs before)
   bool forked;   // work was sent to the auxiliary stream since the last join
 };
 static int g_split_fused = 1;                          // nfk_tune(NFK_TUNE_SPLIT_FUSED)
@@ -93,6 +96,13 @@ static void fork_to_aux(nfk_aux* ax, hipStream_t main_st, int i) {
   ax->forked = true;
   (void)hipEventRecord(ax->ev[i], main_st);
   (void)hipStreamWaitEvent(ax->stream, ax->ev[i], 0);
+}
+static void fork_level_to_aux(nfk_aux* ax, hipStream_t main_st) {
+  hipEvent_t e = ax->lev[ax->lev_next];
+  ax->lev_next = (ax->lev_next + 1) % 16;
+  ax->forked = true;
+  (void)hipEventRecord(e, main_st);
+  (void)hipStreamWaitEvent(ax->stream, e, 0);
 }
 // nfk_step2d_grads.bwd_mode -> 0 separate launches, 1 dual launches for small steps, 2 dual launches, 3 fused backward
 static inline int bwd_mode_of(const nfk_step2d_grads* g) { return g->bwd_mode == NFK_BWD_DEFAULT ? 3 : g->bwd_mode - 1; }
@@ -105,11 +115,14 @@ nfk_aux* nfk_aux_create(void* stream) {
   ax->stream = reinterpret_cast<hipStream_t>(stream);
   for (auto& e : ax->ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ax; return nullptr; }
+  for (auto& e : ax->lev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ax; return nullptr; }
   return ax;
 }
 void nfk_aux_destroy(nfk_aux* ax) {
   if (!ax) return;
   for (auto& e : ax->ev) (void)hipEventDestroy(e);
+  for (auto& e : ax->lev) (void)hipEventDestroy(e);
   delete ax;
 }
 
@@ -731,7 +744,7 @@ int nfk_level2d_bwd(const nfk_level_bwd* lv, const nfk_step2d* host_steps, void*
     int grid = 0;
     NFK_TRY(fusedb_level_launch(fc, st, &grid));
     hipStream_t wst = st;
-    if (ax && ax->stream != st) { fork_to_aux(ax, st, 0); wst = ax->stream; }
+    if (ax && ax->stream != st) { fork_level_to_aux(ax, st); wst = ax->stream; }
     wa.k_lo = lo; wa.k_hi = hi; wa.rows = grid;
     wa.S = level_wgrad_splits(M, s->hidden, L.K3p, L.K1p, hi - lo + 1);
     NFK_TRY(level_wgrad_launch(wa, wst, wst));
