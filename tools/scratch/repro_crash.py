@@ -1,0 +1,41 @@
+import sys, os, faulthandler
+faulthandler.enable()
+ROOT = "/root/repo"
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch
+import test_gpu_fullsize as T
+from golden_util import Golden
+from nf_distillation_amd.pipeline import PipelinedStep
+from nf_distillation_amd.training import CapturedStep
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+g = Golden("distill_full")
+batches = T._distill_batches(g)
+
+def pipelined(dt):
+    step = T._distill_pair(g, dt)
+    step.enable_concurrency()
+    runner = PipelinedStep(step, batches[0][0], use_graph=True, warmup=2, with_noise=True)
+    cur = torch.cuda.current_stream().cuda_stream
+    print(dt, "streams: current", hex(cur), "runner.side", hex(runner.side.cuda_stream), "step._side", hex(step._side.cuda_stream),
+          "step._aux", hex(step._aux.cuda_stream), flush=True)
+    runner.prepare(*batches[0])
+    torch.cuda.synchronize()
+    print(dt, "pipelined prepared ok", flush=True)
+    step.enable_concurrency(False)
+
+def graph(dt):
+    step = T._distill_pair(g, dt)
+    step.enable_concurrency()
+    runner = CapturedStep(step, batches[0][0], warmup=2, with_noise=True)
+    for _ in range(3):
+        runner.training_step(batches[0][0].clone(), batches[0][1], batches[0][2])
+    torch.cuda.synchronize()
+    print(dt, "graph ok", hex(step._aux.cuda_stream), flush=True)
+    step.enable_concurrency(False)
+
+seq = {"all": ["g32", "p32", "g32", "p32", "g16", "p16"], "short": ["p32", "p16"], "only": ["p16"], "gp": ["g16", "p16"],
+       "pp": ["p16", "p16"], "ggp": ["g32", "g16", "p16"]}[which]
+for s in seq:
+    (graph if s[0] == "g" else pipelined)("f32" if s.endswith("32") else "bf16")
+print("done", flush=True)
