@@ -71,8 +71,8 @@ class FlowEngine:
         # backward of the step below) -- or ONE for all steps of a level whose tiles are whole images (`level_multi`) --, then
         # one launch with the level's 3 K weight-gradient GEMMs and one with all reductions.  False: the per-step calls
         # (nfk_step2d_bwd_chain), which the level form is tested against
-        self.level_backward = True
-        self.level_multi = True
+        self.level_backward = os.environ.get("NFK_LEVEL_BACKWARD", "1") != "0"   # (environment knobs: diagnostics)
+        self.level_multi = os.environ.get("NFK_LEVEL_MULTI", "1") != "0"
         # the per-level launches on the auxiliary stream (`aux`, set by training.enable_concurrency; without one they stay on
         # the caller's), joined once per backward: they then run beside the next level's step launches (+3 % of the step)
         self.level_wgrad_aux = os.environ.get("NFK_LEVEL_WGRAD_AUX", "1") != "0"   # (environment knob: diagnostics)

@@ -12,6 +12,7 @@ shape ``[B, C, H, W]`` with channels-last strides (``x.permute(0, 3, 1, 2)`` vie
 import ctypes as C
 import logging
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -463,7 +464,8 @@ class Glow(nn.Module):
         if reverse:
             return self.reverse_flow(z, y_onehot, temperature, eps=eps)
         if keep is not None:
-            if hints_only and not self.is_1d and not self.y_condition and not torch.is_grad_enabled():
+            if (hints_only and not self.is_1d and not self.y_condition and not torch.is_grad_enabled()
+                    and os.environ.get("NFK_HINTS_ONLY", "1") != "0"):
                 return self._forward_all(x, y_onehot, noise, keep, hints_only=True)
             return self.normal_flow(x, y_onehot, noise=noise, keep=keep)
         return self.normal_flow(x, y_onehot, noise=noise)
