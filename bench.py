@@ -117,7 +117,7 @@ def oracle_check(digest, batch, headline_dtype, both):
              "oracle": {k: digest[k] for k in ("nll", "kd", "result_loss", "grad_norm")}, "cases": {}}
     ok = True
     for dt, sched in cases:
-        scal, grads, _ = OC.hip_step(dt, sched, batch)
+        scal, grads, _ = OC.hip_step(dt, sched, batch, level_wgrad_aux=(dt == headline_dtype and sched != "eager"))
         res = OC.compare(digest, scal, grads, dt)
         res.update({k: scal[k] for k in ("nll", "kd", "result_loss", "grad_norm")})
         block["cases"][f"{dt}/{sched}"] = res
@@ -140,6 +140,8 @@ class Leg:
         if args.fused_runs is not None:
             self.teacher.flow.engine().fused_runs = args.fused_runs in ("both", "teacher")
             self.student.flow.engine().fused_runs = args.fused_runs in ("both", "student")
+        # the level backward's per-level launches on the auxiliary stream: +3 % of the one-GPU step, bit-identical (engine.py)
+        self.student.flow.engine().level_wgrad_aux = world == 1 and dtype == args.dtype
         if args.level_backward is not None:   # experiment knob: 0 per-step calls, 1 per level / one launch per step, 2 + runs, 3 + aux
             e = self.student.flow.engine()
             e.level_backward, e.level_multi, e.level_wgrad_aux = args.level_backward >= 1, args.level_backward >= 2, args.level_backward >= 3
@@ -482,8 +484,7 @@ def main():
     check_block = None
     if solo and not args.no_cpu_baseline:
         want = not args.no_oracle_check
-        del leg, other
-        torch.cuda.empty_cache()
+        # (the legs and their captured graphs stay alive to the end of the process: see engine.level_wgrad_aux)
         result["cpu_baseline"], digest = cpu_baseline(args.batch, args.cpu_steps, want_digest=want)
         if want:
             check_block = result["oracle_check"] = oracle_check(digest, args.batch, args.dtype, not args.no_other_precision)

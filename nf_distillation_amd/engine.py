@@ -74,8 +74,13 @@ class FlowEngine:
         self.level_backward = os.environ.get("NFK_LEVEL_BACKWARD", "1") != "0"   # (environment knobs: diagnostics)
         self.level_multi = os.environ.get("NFK_LEVEL_MULTI", "1") != "0"
         # the per-level launches on the auxiliary stream (`aux`, set by training.enable_concurrency; without one they stay on
-        # the caller's), joined once per backward: they then run beside the next level's step launches (+3 % of the step)
-        self.level_wgrad_aux = os.environ.get("NFK_LEVEL_WGRAD_AUX", "1") != "0"   # (environment knob: diagnostics)
+        # the caller's), joined once per backward: they then run beside the next level's step launches (+3 % of the step,
+        # bit-identical: tests/test_gpu_level_bwd.py).  Opt-in (bench.py turns it on for its one-GPU headline leg): with it, a
+        # captured PipelinedStep graph (caller's stream + teacher's side stream + this one) crashed inside hipGraphLaunch
+        # (hip::Graph::UpdateStreams, the HIP runtime bundled with this PyTorch) -- only in a process that had captured and
+        # destroyed other graphs with an auxiliary-stream branch before (tests/test_gpu_fullsize.py in file order; a fresh
+        # process, other orders and the four-stream StagedPipelinedStep graph did not)
+        self.level_wgrad_aux = os.environ.get("NFK_LEVEL_WGRAD_AUX", "0") == "1"
         # ... and, where a level's steps are one launch each, could go out for every `level_wgrad_chunk` steps instead of once
         # per level (0).  Measured and left off: beside the level-1 step launches, which want the whole chip themselves, the
         # chunks cost more than the shorter tail gains (CIFAR B=64: 20 330 images/s at 0, 20 040 / 19 620 / 18 670 at 4 / 2 / 1)

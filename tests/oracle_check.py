@@ -84,7 +84,10 @@ class OptState:
         torch.cuda.synchronize()
 
 
-def hip_step(dtype, schedule, batch, seed=100, device="cuda"):
+_KEEP = []   # runners (and their captured graphs) stay alive for the life of the process (engine.level_wgrad_aux)
+
+
+def hip_step(dtype, schedule, batch, seed=100, device="cuda", level_wgrad_aux=False):
     """The same step through libnfk.  schedule: "eager" (DistillationStep.training_step, one stream), "graph" (the whole
     step as one hipGraph) or "pipelined_graph" (bench.py's default: teacher(t+1) || student(t), one hipGraph).
     -> (scalars dict, {name: unclipped gradient on the device}, schedule actually run)"""
@@ -98,6 +101,7 @@ def hip_step(dtype, schedule, batch, seed=100, device="cuda"):
         m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), sd_seed))
         models.append(m.to(device).set_compute_dtype(dtype))
     step = DistillationStep(models[0], models[1], nll_weight=0.9, kd_weight=0.1, lr=5e-4, clip_norm=30.0)
+    models[0].flow.engine().level_wgrad_aux = bool(level_wgrad_aux)   # (bench.py's headline leg runs with it)
     x, ns, nt = (t.to(device) for t in check_batch(batch, seed))
     ran = schedule
     if schedule == "eager":
@@ -130,6 +134,7 @@ def hip_step(dtype, schedule, batch, seed=100, device="cuda"):
         else:
             raise ValueError(schedule)
         out = {k: v.clone() for k, v in out.items()}
+        _KEEP.append(runner)
     torch.cuda.synchronize()
     scal = {k: float(out[k]) for k in ("nll", "kd", "result_loss")}
     scal["grad_norm"] = float(step.opt.grad_norm())

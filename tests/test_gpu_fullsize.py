@@ -219,7 +219,6 @@ def test_full_size_schedules_are_bit_identical_fp32_and_bf16():
     for dt in ("f32", "bf16"):
         finals = {}
         for schedule in ("eager", "graph", "pipelined_graph"):
-            print("schedules_are_bit_identical:", dt, schedule, flush=True)
             step = _distill_pair(g, dt)
             if schedule == "eager":
                 for x, ns, nt in seq:

@@ -95,7 +95,7 @@ def test_level_backward_on_the_auxiliary_stream_is_bit_identical():
             m.load_state_dict(randomize_state_dict(shapes_of(m.state_dict()), 11))
             m = m.cuda().set_compute_dtype("bf16")
             eng = m.flow.engine()
-            eng.aux, eng.level_wgrad_aux = (aux if use_aux else None), use_aux
+            eng.aux, eng.level_wgrad_aux = (aux if use_aux else None), use_aux   # (opt-in: engine.py)
             _, bpd, _ = m(x.clone().cuda(), None, noise=noise.cuda())
             bpd.mean().backward()
             torch.cuda.synchronize()
