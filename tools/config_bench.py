@@ -82,14 +82,22 @@ def image_case(name, s_cfg, t_cfg, batch, dev, steps=20):
         step.enable_concurrency()
     h, w, c = s_cfg["image_shape"]
     x = (torch.randint(0, 256, (batch, c, h, w), device=dev).float() / 256 - 0.5)
-    runner = CapturedStep(step, x, strict=True)
-    runner.prepare()
-    dt = time_steps(lambda: runner.training_step(x.clone()), steps, 3)
+    if teacher is not None:   # bench.py's default schedule on one GPU: the frozen teacher as two pipeline stages
+        from nf_distillation_amd.pipeline import StagedPipelinedStep
+        runner = StagedPipelinedStep(step, x, strict=True)
+        runner.prepare(x)
+        dt = time_steps(lambda: runner.training_step(x), steps, 3)
+        sched = "hipGraph replay, staged software pipeline (teacher level 1 (t+2) || teacher deep levels (t+1) || student (t))"
+    else:
+        runner = CapturedStep(step, x, strict=True)
+        runner.prepare()
+        dt = time_steps(lambda: runner.training_step(x.clone()), steps, 3)
+        sched = "hipGraph replay"
     gflop = 3 * fwd_gflop_per_image(s_cfg) + (fwd_gflop_per_image(t_cfg) if t_cfg else 0.0)
     tf = batch * gflop / dt / 1e3
     fused_fwd = [int(capi.lib().nfk_step2d_fused_tiles(__import__("ctypes").byref(r.cs)) > 0)
                  for r in student.flow.engine().state["recs"] if r.kind == "step"]
-    return {"config": name, "batch": batch, "images_per_s": batch / dt, "ms_per_step": 1e3 * dt, "schedule": "hipGraph replay",
+    return {"config": name, "batch": batch, "images_per_s": batch / dt, "ms_per_step": 1e3 * dt, "schedule": sched,
             "algorithmic_gflop_per_image": gflop, "achieved_tflops": tf, "roofline": {"bound": "mfma", "peak_tflops": BF16_PEAK,
                                                                                     "frac": tf / BF16_PEAK},
             "student_steps_on_fused_forward": f"{sum(fused_fwd)} of {len(fused_fwd)}"}
