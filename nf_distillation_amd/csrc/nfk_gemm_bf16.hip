@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(256) level_wgrad_kernel(LevelWgradArgs a) {
     return;
   }
   b -= a.nb3 * a.S;
-  {                               // block.0 on the forward's im2col rows: [hid x M] [M x K1p]
+  if (b < a.nb1 * a.S) {          // block.0 on the forward's im2col rows: [hid x M] [M x K1p]
     w.P = gablk + a.o_ga1; w.ldp = a.hid; w.NI = a.hid;
     w.Q = reinterpret_cast<const float*>(a.masks + (long)k * a.mask_stride + a.o_x1); w.ldq = a.K1p; w.Cq = a.K1p; w.J = a.K1p;
     w.out = ws + a.o_s1; w.slab_stride = (long)a.hid * a.K1p;
@@ -1181,7 +1181,9 @@ int level_wgrad_launch(LevelWgradArgs a, hipStream_t st, hipStream_t st_tail) {
   a.nb3 = ceil_div(a.K3p, 128) * ceil_div(a.hid, 128);
   a.nb1 = ceil_div(a.hid, 128) * ceil_div(a.K1p, 128);
   a.nparts = actnorm_sum_parts(a.M);
-  a.per_step = a.nparts + (a.nb2 + a.nb3 + a.nb1) * a.S;
+  // (a multiple of 8: a workgroup's XCD is its index mod 8, and wgrad_bf16_body's remap -- all tiles of one pixel range on one
+  //  XCD's L2 -- counts on the GEMM segments of every step starting on a multiple of 8; surplus workgroups exit at once)
+  a.per_step = (a.nparts + (a.nb2 + a.nb3 + a.nb1) * a.S + 7) & ~7;
   constexpr size_t ldsWide = 2 * WPX * (wg_stride(128) + wg_stride(128));
   static bool attr = false;
   if (!attr) {
