@@ -485,7 +485,8 @@ enum { NFK_TUNE_F32_TILES = 0,               /* fp32 wide conv: 0 default, 1..5 
        NFK_TUNE_WGRAD_HALO = 6,              /* 1/0: conv3's weight gradient through the halo-tile kernel / the generic one */
        NFK_TUNE_WGRAD_HALO_MAX_SPLITS = 7,
        NFK_TUNE_RUN_HALF_TILES = 8,          /* 1/0: runs of steps on tiny images use 32-pixel tiles when the grid is small */
-       NFK_TUNE_SPLIT_FUSED = 9 };           /* 1/0: Split2d forward / backward as one fused fp32 launch each (default 1) */
+       NFK_TUNE_SPLIT_FUSED = 9,             /* 1/0: Split2d forward / backward as one fused fp32 launch each (default 1) */
+       NFK_TUNE_TAB_RESIDENT = 10 };         /* 1/0: 1-D kernels keep every weight matrix resident in LDS per workgroup (default 1) / stage per tile */
 void nfk_tune(int knob, int value);
 void nfk_profile_end(double *ms, long long *launches, double *flops, double *bytes);
 

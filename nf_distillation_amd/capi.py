@@ -117,7 +117,7 @@ KD_MAX_PAIRS = 16   # NFK_KD_MAX_PAIRS
 BWD_DEFAULT, BWD_SEPARATE, BWD_DUAL_SMALL, BWD_DUAL, BWD_FUSED = 0, 1, 2, 3, 4
 # nfk_tune knobs
 (TUNE_F32_TILES, TUNE_BF16_BIG_TILE_MIN_K64, TUNE_WGRAD_MAX_SPLITS, TUNE_WGRAD_TARGET_WGS, TUNE_WGRAD_WIDE_MAX_SPLITS,
- TUNE_NARROW_HALO_DGRAD, TUNE_WGRAD_HALO, TUNE_WGRAD_HALO_MAX_SPLITS, TUNE_RUN_HALF_TILES, TUNE_SPLIT_FUSED) = range(10)
+ TUNE_NARROW_HALO_DGRAD, TUNE_WGRAD_HALO, TUNE_WGRAD_HALO_MAX_SPLITS, TUNE_RUN_HALF_TILES, TUNE_SPLIT_FUSED, TUNE_TAB_RESIDENT) = range(11)
 
 
 class KdPairs(C.Structure):

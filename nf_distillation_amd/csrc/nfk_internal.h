@@ -154,6 +154,7 @@ void triple_wgrad_debug_skip(int mask);
 int fused2_tiles(const nfk_step2d& s);   // log-det partial slots per sample, 0 = shape not supported
 void fused2_set_half_tiles(int on);
 void fusedb_set_small_tiles(int on);
+void tab_set_resident(int on);
 int fused2_launch(const FusedCall& c, hipStream_t st);
 size_t fused2_ws_floats(const nfk_step2d& s);
 

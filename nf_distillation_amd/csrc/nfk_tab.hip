@@ -50,9 +50,24 @@ __host__ __device__ static inline int tab_param_off(const TabStep& s, int l) {
 struct TabLds {
   int TR, XS, HS, OS, IS, GS;
   float *X, *Y, *IN0, *H[5], *O, *GA, *GB, *GY, *Wl, *Pl, *PM;
+  // resident mode (round 3): every weight matrix of the step stays in LDS for the life of the workgroup, in the forward
+  // layout [inputs][pad4(outputs) + 4] (slot 0: the channel mix Wf, 1..6: the MLP's layers), with its bias vector
+  float* WR[7];
+  float* BR[7];
+  int res;
 };
+constexpr int TAB_PACC_MAX = 96;   // resident backward: weight-gradient sums per thread (private memory instead of LDS)
 
-__host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds* L, float* base) {
+__host__ __device__ static inline int tab_res_stride(int nout) { return pad4(nout) + 4; }   // rows 16-byte aligned, banks spread
+__host__ __device__ static inline int tab_w_in(const TabStep& s, int k) { return k == 0 ? s.d : tab_layer_in(s, k - 1); }
+__host__ __device__ static inline int tab_w_out(const TabStep& s, int k) { return k == 0 ? s.d : tab_layer_out(s, k - 1); }
+__host__ __device__ static inline int tab_pacc_slots(const TabStep& s) {
+  int t = (s.d * s.d + s.d + 255) / 256;
+  for (int l = 0; l < 6; ++l) t += (tab_layer_out(s, l) * (tab_layer_in(s, l) + 1) + 255) / 256;
+  return t;
+}
+
+__host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds* L, float* base, bool res = false) {
   const int d = s.d, hid = s.hid, nout = tab_nout(s), nin0 = tab_nin0(s);
   const int TR = tab_rows(hid, d);
   int mx = d > hid ? d : hid;
@@ -60,7 +75,8 @@ __host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, 
   if (nin0 > mx) mx = nin0;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~size_t(3); return r; };
-  const int XS = d + 1, HS = hid + 1, OS = nout + 1, IS = nin0 + 1, GS = mx + 1;
+  // (resident backward: gradient rows 16-byte aligned -- its transposed layers read four of them as float4 beside a weight row)
+  const int XS = d + 1, HS = hid + 1, OS = nout + 1, IS = nin0 + 1, GS = (res && bwd) ? pad4(mx) + 4 : mx + 1;
   size_t oX = take((size_t)TR * XS), oY = take((size_t)TR * XS), oI = take((size_t)TR * IS);
   size_t oH[5];
   for (int k = 0; k < 5; ++k) oH[k] = take((size_t)TR * HS);
@@ -73,18 +89,26 @@ __host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, 
                          (size_t)hid * pad4(nin0), (size_t)nout * pad4(hid)};
     for (size_t v : c) if (v > wmax) wmax = v;
   }
-  size_t oW = take(wmax);
+  size_t oW = res ? 0 : take(wmax);
   size_t oGA = 0, oGB = 0, oGY = 0, oP = 0, oPM = 0;
   if (bwd) {
-    oGA = take((size_t)TR * GS); oGB = take((size_t)TR * GS); oGY = take((size_t)TR * XS);
-    oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d);
+    oGA = take((size_t)TR * GS); oGB = take((size_t)TR * GS); oGY = take((size_t)TR * (res ? GS : XS));
+    if (!res) { oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d); }
   }
+  size_t oWR[7] = {0, 0, 0, 0, 0, 0, 0}, oBR[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (res)
+    for (int k = 0; k < 7; ++k) {
+      oWR[k] = take((size_t)tab_w_in(s, k) * tab_res_stride(tab_w_out(s, k)));
+      oBR[k] = take((size_t)tab_w_out(s, k));
+    }
   if (L) {
     L->TR = TR; L->XS = XS; L->HS = HS; L->OS = OS; L->IS = IS; L->GS = GS;
     L->X = base + oX; L->Y = base + oY; L->IN0 = base + oI;
     for (int k = 0; k < 5; ++k) L->H[k] = base + oH[k];
     L->O = base + oO; L->Wl = base + oW;
     L->GA = base + oGA; L->GB = base + oGB; L->GY = base + oGY; L->Pl = base + oP; L->PM = base + oPM;
+    L->res = res ? 1 : 0;
+    for (int k = 0; k < 7; ++k) { L->WR[k] = base + oWR[k]; L->BR[k] = base + oBR[k]; }
   }
   return o * sizeof(float);
 }
@@ -127,6 +151,78 @@ __device__ void tab_dense(const float* in, int ldi, int nin, const float* __rest
   __syncthreads();
 }
 
+// ---- resident mode: weights staged ONCE per workgroup.  (Per tile and layer the staging above is a round trip to L2 for
+// ~1 K floats in front of 16 rows x 32 outputs of arithmetic: at d = 63 it was most of the forward's time and, fourteen times
+// per tile, of the backward's.)
+__device__ void tab_stage_resident(const TabStep& s, const TabLds& L) {
+  for (int k = 0; k < 7; ++k) {
+    const int nin = tab_w_in(s, k), nout = tab_w_out(s, k), rs = tab_res_stride(nout);
+    const float* __restrict__ W = k == 0 ? s.Wf : s.W[k - 1];
+    const float* __restrict__ b = k == 0 ? s.cf : s.b[k - 1];
+    for (int idx = threadIdx.x; idx < nin * rs; idx += blockDim.x) {
+      const int c = idx / rs, o = idx - c * rs;
+      L.WR[k][idx] = o < nout ? W[o * nin + c] : 0.f;      // nn.Linear [out][in] -> [in][out + pad], pad columns zero
+    }
+    for (int o = threadIdx.x; o < nout; o += blockDim.x) L.BR[k][o] = b[o];
+  }
+  __syncthreads();
+}
+// out[p][o] = act(sum_c in[p][c] W[o][c] + b[o]) on the resident copy (Wr = [nin][rs], br in LDS or null).  One barrier, at
+// the end (the caller's previous phase ended with one).
+__device__ void tab_dense_res(const float* in, int ldi, int nin, const float* Wr, const float* br, float* out, int ldo, int nout,
+                              int act, int TR) {
+  const int rs = tab_res_stride(nout), G4 = pad4(nout) / 4;
+  for (int t = threadIdx.x; t < TR * G4; t += blockDim.x) {
+    const int p = t / G4, o = (t - p * G4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (br)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (o + r < nout) acc[r] = br[o + r];
+    const float* xr = in + p * ldi;
+#pragma unroll 4
+    for (int c = 0; c < nin; ++c) {
+      const float xv = xr[c];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(Wr + c * rs + o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (o + r < nout) {
+        float v = acc[r];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = tanhf(v);
+        out[p * ldo + o + r] = v;
+      }
+  }
+  __syncthreads();
+}
+// The transposed layer on the SAME resident copy:  out[p][c] = sum_o g[p][o] W[o][c] = dot(g[p][:], Wr[c][:])  -- a weight row
+// (contiguous over o, 16-byte pieces) against FOUR gradient rows per thread (g rows 16-byte aligned: ldg % 4 == 0, TR % 4 == 0).
+// nred = the forward layer's outputs (reduction length), nout_t = its inputs.  Pad columns of Wr are zero; g's pad entries are
+// kept finite by the callers (zeroed once per workgroup).
+__device__ void tab_dense_res_t(const float* g, int ldg, int nred, const float* Wr, float* out, int ldo, int nout_t, int TR) {
+  const int rs = tab_res_stride(nred), n4 = pad4(nred), PG = TR / 4;
+  for (int t = threadIdx.x; t < nout_t * PG; t += blockDim.x) {
+    const int pg = t / nout_t, c = t - pg * nout_t;
+    const float* wrow = Wr + c * rs;
+    const float* g0 = g + (pg * 4) * ldg;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int o = 0; o < n4; o += 4) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g0 + r * ldg + o);
+        acc[r] += (w[0] * gv[0] + w[1] * gv[1]) + (w[2] * gv[2] + w[3] * gv[3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(pg * 4 + r) * ldo + c] = acc[r];
+  }
+  __syncthreads();
+}
+
 // Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
 __device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0) {
   const int d = s.d, TR = L.TR;
@@ -134,7 +230,8 @@ __device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float*
     const int p = idx / d, c = idx - p * d, m = row0 + p;
     L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
   }
-  tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
+  if (L.res) { __syncthreads(); tab_dense_res(L.X, L.XS, d, L.WR[0], L.BR[0], L.Y, L.XS, d, 0, TR); }
+  else tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
   const int nin0 = tab_nin0(s), nf = tab_nfeat(s);
   for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
     const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
@@ -145,6 +242,16 @@ __device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float*
   }
   const float* in = L.IN0;
   int ldi = L.IS;
+  if (L.res) {
+    __syncthreads();
+    for (int l = 0; l < 5; ++l) {
+      tab_dense_res(in, ldi, tab_layer_in(s, l), L.WR[l + 1], L.BR[l + 1], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, TR);
+      in = L.H[l];
+      ldi = L.HS;
+    }
+    tab_dense_res(L.H[4], L.HS, s.hid, L.WR[6], L.BR[6], L.O, L.OS, tab_nout(s), 0, TR);
+    return;
+  }
   for (int l = 0; l < 5; ++l) {
     tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
     in = L.H[l];
@@ -155,10 +262,11 @@ __device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float*
 
 __global__ void __launch_bounds__(256) tab_fwd_kernel(TabStep s, const float* __restrict__ x,
                                                       const float* __restrict__ cond, const float* __restrict__ ld_in,
-                                                      float* __restrict__ zout, float* __restrict__ ld_out) {
+                                                      float* __restrict__ zout, float* __restrict__ ld_out, int res) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, false, &L, smem);
+  tab_layout(s, false, &L, smem, res != 0);
+  if (res) tab_stage_resident(s, L);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR;
   const int ntiles = (s.B + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -440,6 +548,146 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
   for (int i = threadIdx.x; i < NM; i += blockDim.x) part_mix[(long)blockIdx.x * NM + i] = L.PM[i];
 }
 
+// ---- resident backward (round 3).  As tab_bwd_kernel, with every weight matrix resident in LDS (tab_stage_resident), the
+// transposed layers as row dot products on the same copies (tab_dense_res_t: no transposed staging), and the per-workgroup
+// weight-gradient sums in private memory (TAB_PACC_MAX values per thread: thread t owns elements t, t + 256, ... of every
+// layer's [out][in + 1] block, exactly the elements it owned in the LDS version -- same sums in the same order).
+__device__ void tab_wgrad_acc(const float* g, int ldg, const float* in, int ldi, int nin, int nout, float* pacc, int kbase, int TR) {
+  int k = kbase;
+  for (int idx = threadIdx.x; idx < nout * (nin + 1); idx += blockDim.x, ++k) {
+    const int o = idx / (nin + 1), c = idx - o * (nin + 1);
+    float sacc = 0.f;
+    if (c < nin) {
+#pragma unroll 4
+      for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o] * in[p * ldi + c];
+    } else {
+#pragma unroll 4
+      for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
+    }
+    pacc[k] += sacc;
+  }
+}
+
+__global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float* __restrict__ x, const float* __restrict__ cond,
+                                                          const float* __restrict__ gout, const float* __restrict__ gld,
+                                                          float* __restrict__ gx, float* __restrict__ gcond,
+                                                          float* __restrict__ part, float* __restrict__ part_mix) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TabLds L;
+  tab_layout(s, true, &L, smem, true);
+  const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s), YS = L.GS;   // (GY rows: the aligned stride)
+  const int NP = tab_param_floats(s), NM = d * d + d;
+  float pacc[TAB_PACC_MAX];
+#pragma unroll
+  for (int i = 0; i < TAB_PACC_MAX; ++i) pacc[i] = 0.f;
+  for (int i = threadIdx.x; i < TR * L.GS; i += blockDim.x) { L.GA[i] = 0.f; L.GB[i] = 0.f; L.GY[i] = 0.f; }   // pad columns finite
+  tab_stage_resident(s, L);
+  int kb[7];   // first private slot of layer l (0..5), then of the channel mix
+  {
+    int t = 0;
+    for (int l = 0; l < 6; ++l) { kb[l] = t; t += (tab_layer_out(s, l) * (tab_layer_in(s, l) + 1) + 255) / 256; }
+    kb[6] = t;
+  }
+  const int ntiles = (s.B + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TR;
+    tab_forward_tile(s, L, x, cond, row0);
+    // ---- tail backward: grads wrt O (into GA) and wrt y2 (into GY second half)
+    if (s.made)
+      for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+        const int p = idx / d, j = idx - p * d, m = row0 + p;
+        const float gu = m < s.B ? gout[(long)m * d + j] : 0.f;
+        const float gl = (m < s.B && gld) ? gld[m] : 0.f;
+        const float mu = L.O[p * L.OS + 2 * j], al = L.O[p * L.OS + 2 * j + 1], e = expf(-al);
+        const float u = (L.Y[p * L.XS + j] - mu) * e;
+        L.GA[p * L.GS + 2 * j] = -gu * e;
+        L.GA[p * L.GS + 2 * j + 1] = m < s.B ? -gu * u - gl : 0.f;
+        L.GY[p * YS + j] = gu * e;
+      }
+    else
+      for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
+        const int p = idx / C2, j = idx - p * C2, m = row0 + p;
+        const float g2 = m < s.B ? gout[(long)m * d + Ch + j] : 0.f;
+        const float gl = (m < s.B && gld) ? gld[m] : 0.f;
+        if (s.additive) {
+          L.GA[p * L.GS + j] = g2;
+          L.GY[p * YS + Ch + j] = g2;
+        } else {
+          const float shf = L.O[p * L.OS + 2 * j], sr = L.O[p * L.OS + 2 * j + 1];
+          const float sc = sigmoidf(sr + 2.f), z2 = L.Y[p * L.XS + Ch + j];
+          const float gshift = g2 * sc;
+          L.GA[p * L.GS + 2 * j] = gshift;
+          L.GA[p * L.GS + 2 * j + 1] = (m < s.B) ? g2 * (z2 + shf) * sc * (1.f - sc) + gl * (1.f - sc) : 0.f;
+          L.GY[p * YS + Ch + j] = gshift;
+        }
+      }
+    __syncthreads();
+    // ---- MLP backward, layers 5..0
+    float* g = L.GA;
+    float* gn = L.GB;
+    for (int l = 5; l >= 0; --l) {
+      const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
+      const float* in = l == 0 ? L.IN0 : L.H[l - 1];
+      const int ldi = l == 0 ? L.IS : L.HS;
+      tab_wgrad_acc(g, L.GS, in, ldi, nin, no, pacc, kb[l], TR);
+      tab_dense_res_t(g, L.GS, no, L.WR[l + 1], gn, L.GS, nin, TR);
+      if (l > 0) {
+        const int act = (l - 1) == 4 ? 2 : 1;
+        for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
+          const int p = idx / nin, c = idx - p * nin;
+          const float h = L.H[l - 1][p * L.HS + c];
+          gn[p * L.GS + c] *= act == 1 ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
+        }
+        __syncthreads();
+      }
+      float* t = g; g = gn; gn = t;
+    }
+    // g = grad wrt IN0 = (z1 | cond)   (MADE: (y | cond), added to the direct term of the tail)
+    const int nf = tab_nfeat(s);
+    for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
+      const int p = idx / nin0, c = idx - p * nin0, m = row0 + p;
+      if (c < nf) {
+        if (s.made) L.GY[p * YS + c] += g[p * L.GS + c];
+        else L.GY[p * YS + c] = g[p * L.GS + c] + (m < s.B ? gout[(long)m * d + c] : 0.f);
+      } else if (gcond && m < s.B) gcond[(long)m * s.ncond + (c - nf)] += g[p * L.GS + c];
+    }
+    __syncthreads();
+    // ---- mix backward: partial (gWf, gcf); gx = Wf^T gy
+    {
+      int k = kb[6];
+      for (int idx = threadIdx.x; idx < NM; idx += blockDim.x, ++k) {
+        float sacc = 0.f;
+        if (idx < d * d) {
+          const int o = idx / d, c = idx - o * d;
+#pragma unroll 4
+          for (int p = 0; p < TR; ++p) sacc += L.GY[p * YS + o] * L.X[p * L.XS + c];
+        } else {
+          const int o = idx - d * d;
+#pragma unroll 4
+          for (int p = 0; p < TR; ++p) sacc += L.GY[p * YS + o];
+        }
+        pacc[k] += sacc;
+      }
+    }
+    tab_dense_res_t(L.GY, YS, d, L.WR[0], gn, L.GS, d, TR);
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      if (m < s.B) gx[(long)m * d + c] = gn[p * L.GS + c];
+    }
+    __syncthreads();
+  }
+  // the workgroup's slab of partial sums, in the layout tab_reduce_kernel / nfk_prep_bwd read
+  for (int l = 0; l < 6; ++l) {
+    const int n = tab_layer_out(s, l) * (tab_layer_in(s, l) + 1), off = tab_param_off(s, l);
+    int k = kb[l];
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x, ++k) part[(long)blockIdx.x * NP + off + idx] = pacc[k];
+  }
+  {
+    int k = kb[6];
+    for (int idx = threadIdx.x; idx < NM; idx += blockDim.x, ++k) part_mix[(long)blockIdx.x * NM + idx] = pacc[k];
+  }
+}
+
 // Backward of tab_inv_kernel (the reverse / sampling pass with gradients: the perceptual branch of the tabular
 // distillation loss, pl_module.py:229-243).  Given g_x = dL/dx of the step's reverse OUTPUT x = Wi z + ci:
 //   g_z = Wi^T g_x, partial (g_Wi, g_ci)            -> part_mix (same [d*d + d] layout as the forward's (gWf, gcf))
@@ -584,6 +832,20 @@ static int tab_check(const TabStep& s, bool bwd, size_t* lds) {
   *lds = tab_layout(s, bwd, nullptr, nullptr);
   return *lds > 160 * 1024 ? NFK_ERR_ARG : NFK_OK;
 }
+static int g_tab_resident = 1;   // experiment knob (NFK_TUNE_TAB_RESIDENT): 0 = the per-tile staging of rounds 1-2
+// resident mode: every weight matrix in LDS for the life of the workgroup -- if the layout fits, the tile has a multiple of
+// four rows (the transposed layers take four gradient rows per thread) and, backward, the private sums fit their slots
+static bool tab_resident_ok(const TabStep& s, bool bwd, size_t* lds) {
+  if (!g_tab_resident) return false;
+  const int TR = tab_rows(s.hid, s.d);
+  if (TR < 4 || (TR & 3)) return false;
+  if (bwd && tab_pacc_slots(s) > TAB_PACC_MAX) return false;
+  const size_t n = tab_layout(s, bwd, nullptr, nullptr, true);
+  if (n > 160 * 1024 - 1024) return false;
+  *lds = n;
+  return true;
+}
+void tab_set_resident(int on) { g_tab_resident = on; }
 
 }  // namespace nfk
 
@@ -600,8 +862,17 @@ int nfk_tab_fwd(const nfk_tab_step* s, const float* x, const float* cond, const 
   if (s->B == 0) return NFK_OK;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-  hipLaunchKernelGGL(tab_fwd_kernel, dim3(tab_blocks(*s, false)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                     *s, x, cond, ld_in, zout, ld_out);
+  size_t lds_r;
+  const bool res = tab_resident_ok(*s, false, &lds_r);
+  int nb = tab_blocks(*s, false);
+  if (res) {   // a workgroup stages the weights once and then walks its tiles: as many as fit the chip, no more
+    lds = lds_r;
+    const int per_cu = (int)((160 * 1024) / (lds_r + 1024));
+    const int cap = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (nb > cap) nb = cap;
+  }
+  hipLaunchKernelGGL(tab_fwd_kernel, dim3(nb), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                     *s, x, cond, ld_in, zout, ld_out, res ? 1 : 0);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
@@ -627,7 +898,14 @@ int nfk_tab_bwd(const nfk_tab_step* s, const nfk_tab_grads* g, const float* x, c
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   const int nb = tab_blocks(*s, true);
-  hipLaunchKernelGGL(tab_bwd_kernel, dim3(nb), dim3(256), lds, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
+  size_t lds_r;
+  if (tab_resident_ok(*s, true, &lds_r)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_bwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    hipLaunchKernelGGL(tab_bwd_res_kernel, dim3(nb), dim3(256), lds_r, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
+  } else {
+    hipLaunchKernelGGL(tab_bwd_kernel, dim3(nb), dim3(256), lds, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
+  }
   NFK_LAUNCH_CHECK();
   hipLaunchKernelGGL(tab_reduce_kernel, dim3(ceil_div(tab_param_floats(*s), 256)), dim3(256), 0, st, *s, *g, part, nb);
   NFK_LAUNCH_CHECK();
