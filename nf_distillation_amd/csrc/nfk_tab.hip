@@ -76,7 +76,10 @@ __host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, 
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~size_t(3); return r; };
   // (resident backward: gradient rows 16-byte aligned -- its transposed layers read four of them as float4 beside a weight row)
-  const int XS = d + 1, HS = hid + 1, OS = nout + 1, IS = nin0 + 1, GS = (res && bwd) ? pad4(mx) + 4 : mx + 1;
+  // row strides: odd (rows p, p + 1, ... of a tile on different banks: lanes of a wave differ in p) -- "n + 1" alone left d = 63
+  // with 64-float rows, every row on the same bank
+  const int XS = (d + 1) | 1, HS = (hid + 1) | 1, OS = (nout + 1) | 1, IS = (nin0 + 1) | 1,
+            GS = (res && bwd) ? pad4(mx) + 4 : ((mx + 1) | 1);
   size_t oX = take((size_t)TR * XS), oY = take((size_t)TR * XS), oI = take((size_t)TR * IS);
   size_t oH[5];
   for (int k = 0; k < 5; ++k) oH[k] = take((size_t)TR * HS);
