@@ -49,25 +49,32 @@ __host__ __device__ static inline int tab_param_off(const TabStep& s, int l) {
 
 struct TabLds {
   int TR, XS, HS, OS, IS, GS;
-  float *X, *Y, *IN0, *H[5], *O, *GA, *GB, *GY, *Wl, *Pl, *PM;
+  float *X, *Y, *IN0, *H0, *O, *GA, *GB, *GY, *Wl, *Pl, *PM;
+  int HST;   // floats between the five hidden-activation buffers: H(k) = H0 + k * HST.  (No arrays of pointers in here: indexed
+             // with a run-time layer number they put the whole struct into scratch memory, a round trip per use.)
+  __host__ __device__ float* H(int k) const { return H0 + k * HST; }
   // resident mode (round 3): every weight matrix of the step stays in LDS for the life of the workgroup, in the forward
   // layout [inputs][pad4(outputs) + 4] (slot 0: the channel mix Wf, 1..6: the MLP's layers), with its bias vector
-  float* WR[7];
-  float* BR[7];
+  float* WR0;   // WR(k) = WR0 + tab_wr_off(s, k), BR(k) behind it (tab_wr / tab_br)
   int res;
 };
-constexpr int TAB_PACC_MAX = 96;   // resident backward: weight-gradient sums per thread (private memory instead of LDS)
 
 __host__ __device__ static inline int tab_res_stride(int nout) { return pad4(nout) + 4; }   // rows 16-byte aligned, banks spread
 __host__ __device__ static inline int tab_w_in(const TabStep& s, int k) { return k == 0 ? s.d : tab_layer_in(s, k - 1); }
 __host__ __device__ static inline int tab_w_out(const TabStep& s, int k) { return k == 0 ? s.d : tab_layer_out(s, k - 1); }
-__host__ __device__ static inline int tab_pacc_slots(const TabStep& s) {
-  int t = (s.d * s.d + s.d + 255) / 256;
-  for (int l = 0; l < 6; ++l) t += (tab_layer_out(s, l) * (tab_layer_in(s, l) + 1) + 255) / 256;
+// floats in front of resident matrix k (k = 7: all of them): matrix [inputs][stride], then its bias vector, each padded to 4
+__host__ __device__ static inline int tab_wr_off(const TabStep& s, int k) {
+  int t = 0;
+  for (int j = 0; j < k; ++j) t += pad4(tab_w_in(s, j) * tab_res_stride(tab_w_out(s, j))) + pad4(tab_w_out(s, j));
   return t;
 }
+__host__ __device__ static inline float* tab_wr(const TabStep& s, const TabLds& L, int k) { return L.WR0 + tab_wr_off(s, k); }
+__host__ __device__ static inline float* tab_br(const TabStep& s, const TabLds& L, int k) {
+  return L.WR0 + tab_wr_off(s, k) + pad4(tab_w_in(s, k) * tab_res_stride(tab_w_out(s, k)));
+}
 
-__host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds* L, float* base, bool res = false) {
+__host__ __device__ __attribute__((always_inline)) static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds& Lr, float* base, bool res = false) {
+  TabLds* const L = &Lr;   // (a reference: a null test on a private-memory address pins the struct in scratch memory)
   const int d = s.d, hid = s.hid, nout = tab_nout(s), nin0 = tab_nin0(s);
   const int TR = tab_rows(hid, d);
   int mx = d > hid ? d : hid;
@@ -81,8 +88,8 @@ __host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, 
   const int XS = (d + 1) | 1, HS = (hid + 1) | 1, OS = (nout + 1) | 1, IS = (nin0 + 1) | 1,
             GS = (res && bwd) ? pad4(mx) + 4 : ((mx + 1) | 1);
   size_t oX = take((size_t)TR * XS), oY = take((size_t)TR * XS), oI = take((size_t)TR * IS);
-  size_t oH[5];
-  for (int k = 0; k < 5; ++k) oH[k] = take((size_t)TR * HS);
+  const size_t hst = ((size_t)TR * HS + 3) & ~size_t(3);
+  size_t oH = take(5 * hst);
   size_t oO = take((size_t)TR * OS);
   // staged weights of one dense layer [inputs][pad4(outputs)]: the largest of the layers' shapes (and their transposes in
   // the backward), not mx x mx -- with 2 d outputs (MADE, d = 63) that alone would be 64 KiB
@@ -90,28 +97,28 @@ __host__ __device__ static inline size_t tab_layout(const TabStep& s, bool bwd, 
   {
     const size_t c[5] = {(size_t)nin0 * pad4(hid), (size_t)hid * pad4(hid), (size_t)hid * pad4(nout),
                          (size_t)hid * pad4(nin0), (size_t)nout * pad4(hid)};
-    for (size_t v : c) if (v > wmax) wmax = v;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) if (c[i] > wmax) wmax = c[i];
   }
   size_t oW = res ? 0 : take(wmax);
   size_t oGA = 0, oGB = 0, oGY = 0, oP = 0, oPM = 0;
   if (bwd) {
     oGA = take((size_t)TR * GS); oGB = take((size_t)TR * GS); oGY = take((size_t)TR * (res ? GS : XS));
-    if (!res) { oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d); }
+    oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d);
   }
-  size_t oWR[7] = {0, 0, 0, 0, 0, 0, 0}, oBR[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (res)
-    for (int k = 0; k < 7; ++k) {
-      oWR[k] = take((size_t)tab_w_in(s, k) * tab_res_stride(tab_w_out(s, k)));
-      oBR[k] = take((size_t)tab_w_out(s, k));
-    }
-  if (L) {
+  size_t oWR = 0;
+  if (res) {
+    oWR = o;
+    o += tab_wr_off(s, 7);
+  }
+  {
     L->TR = TR; L->XS = XS; L->HS = HS; L->OS = OS; L->IS = IS; L->GS = GS;
     L->X = base + oX; L->Y = base + oY; L->IN0 = base + oI;
-    for (int k = 0; k < 5; ++k) L->H[k] = base + oH[k];
+    L->H0 = base + oH; L->HST = (int)hst;
     L->O = base + oO; L->Wl = base + oW;
     L->GA = base + oGA; L->GB = base + oGB; L->GY = base + oGY; L->Pl = base + oP; L->PM = base + oPM;
     L->res = res ? 1 : 0;
-    for (int k = 0; k < 7; ++k) { L->WR[k] = base + oWR[k]; L->BR[k] = base + oBR[k]; }
+    L->WR0 = base + oWR;
   }
   return o * sizeof(float);
 }
@@ -157,16 +164,19 @@ __device__ void tab_dense(const float* in, int ldi, int nin, const float* __rest
 // ---- resident mode: weights staged ONCE per workgroup.  (Per tile and layer the staging above is a round trip to L2 for
 // ~1 K floats in front of 16 rows x 32 outputs of arithmetic: at d = 63 it was most of the forward's time and, fourteen times
 // per tile, of the backward's.)
-__device__ void tab_stage_resident(const TabStep& s, const TabLds& L) {
+__device__ __forceinline__ void tab_stage_resident(const TabStep& s, const TabLds& L) {
+#pragma unroll
   for (int k = 0; k < 7; ++k) {
     const int nin = tab_w_in(s, k), nout = tab_w_out(s, k), rs = tab_res_stride(nout);
-    const float* __restrict__ W = k == 0 ? s.Wf : s.W[k - 1];
-    const float* __restrict__ b = k == 0 ? s.cf : s.b[k - 1];
+    const float* __restrict__ W = k == 0 ? s.Wf : s.W[k > 0 ? k - 1 : 0];
+    const float* __restrict__ b = k == 0 ? s.cf : s.b[k > 0 ? k - 1 : 0];
+    float* wr = tab_wr(s, L, k);
+    float* br = tab_br(s, L, k);
     for (int idx = threadIdx.x; idx < nin * rs; idx += blockDim.x) {
       const int c = idx / rs, o = idx - c * rs;
-      L.WR[k][idx] = o < nout ? W[o * nin + c] : 0.f;      // nn.Linear [out][in] -> [in][out + pad], pad columns zero
+      wr[idx] = o < nout ? W[o * nin + c] : 0.f;      // nn.Linear [out][in] -> [in][out + pad], pad columns zero
     }
-    for (int o = threadIdx.x; o < nout; o += blockDim.x) L.BR[k][o] = b[o];
+    for (int o = threadIdx.x; o < nout; o += blockDim.x) br[o] = b[o];
   }
   __syncthreads();
 }
@@ -227,13 +237,13 @@ __device__ void tab_dense_res_t(const float* g, int ldg, int nred, const float* 
 }
 
 // Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
-__device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0) {
+__device__ __forceinline__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0) {
   const int d = s.d, TR = L.TR;
   for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
     const int p = idx / d, c = idx - p * d, m = row0 + p;
     L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
   }
-  if (L.res) { __syncthreads(); tab_dense_res(L.X, L.XS, d, L.WR[0], L.BR[0], L.Y, L.XS, d, 0, TR); }
+  if (L.res) { __syncthreads(); tab_dense_res(L.X, L.XS, d, tab_wr(s, L, 0), tab_br(s, L, 0), L.Y, L.XS, d, 0, TR); }
   else tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
   const int nin0 = tab_nin0(s), nf = tab_nfeat(s);
   for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
@@ -247,20 +257,21 @@ __device__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float*
   int ldi = L.IS;
   if (L.res) {
     __syncthreads();
+#pragma unroll
     for (int l = 0; l < 5; ++l) {
-      tab_dense_res(in, ldi, tab_layer_in(s, l), L.WR[l + 1], L.BR[l + 1], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, TR);
-      in = L.H[l];
+      tab_dense_res(in, ldi, tab_layer_in(s, l), tab_wr(s, L, l + 1), tab_br(s, L, l + 1), L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, TR);
+      in = L.H(l);
       ldi = L.HS;
     }
-    tab_dense_res(L.H[4], L.HS, s.hid, L.WR[6], L.BR[6], L.O, L.OS, tab_nout(s), 0, TR);
+    tab_dense_res(L.H(4), L.HS, s.hid, tab_wr(s, L, 6), tab_br(s, L, 6), L.O, L.OS, tab_nout(s), 0, TR);
     return;
   }
   for (int l = 0; l < 5; ++l) {
-    tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
-    in = L.H[l];
+    tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+    in = L.H(l);
     ldi = L.HS;
   }
-  tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+  tab_dense(L.H(4), L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
 }
 
 __global__ void __launch_bounds__(256) tab_fwd_kernel(TabStep s, const float* __restrict__ x,
@@ -268,7 +279,7 @@ __global__ void __launch_bounds__(256) tab_fwd_kernel(TabStep s, const float* __
                                                       float* __restrict__ zout, float* __restrict__ ld_out, int res) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, false, &L, smem, res != 0);
+  tab_layout(s, false, L, smem, res != 0);
   if (res) tab_stage_resident(s, L);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR;
   const int ntiles = (s.B + TR - 1) / TR;
@@ -333,7 +344,7 @@ __global__ void __launch_bounds__(256) tab_inv_kernel(TabStep s, const float* __
                                                       float* __restrict__ xout, float* __restrict__ ld_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, false, &L, smem);
+  tab_layout(s, false, L, smem);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s);
   const int ntiles = (s.B + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -361,11 +372,11 @@ __global__ void __launch_bounds__(256) tab_inv_kernel(TabStep s, const float* __
         const float* in = L.IN0;
         int ldi = L.IS;
         for (int l = 0; l < 5; ++l) {
-          tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
-          in = L.H[l];
+          tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+          in = L.H(l);
           ldi = L.HS;
         }
-        tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+        tab_dense(L.H(4), L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
         for (int p = threadIdx.x; p < TR; p += blockDim.x)
           L.Y[p * L.XS + i] = L.X[p * L.XS + i] * expf(L.O[p * L.OS + 2 * i + 1]) + L.O[p * L.OS + 2 * i];
         __syncthreads();
@@ -394,11 +405,11 @@ __global__ void __launch_bounds__(256) tab_inv_kernel(TabStep s, const float* __
     const float* in = L.IN0;
     int ldi = L.IS;
     for (int l = 0; l < 5; ++l) {
-      tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
-      in = L.H[l];
+      tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+      in = L.H(l);
       ldi = L.HS;
     }
-    tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+    tab_dense(L.H(4), L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
     for (int idx = threadIdx.x; idx < TR * C2; idx += blockDim.x) {
       const int p = idx / C2, j = idx - p * C2;
       const float y2 = L.Y[p * L.XS + Ch + j];
@@ -435,8 +446,13 @@ __device__ void tab_wgrad(const float* g, int ldg, const float* in, int ldi, int
   for (int idx = threadIdx.x; idx < nout * (nin + 1); idx += blockDim.x) {
     const int o = idx / (nin + 1), c = idx - o * (nin + 1);
     float sacc = 0.f;
-    if (c < nin) for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o] * in[p * ldi + c];
-    else for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
+    if (c < nin) {
+#pragma unroll 4
+      for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o] * in[p * ldi + c];
+    } else {
+#pragma unroll 4
+      for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
+    }
     P[idx] += sacc;
   }
 }
@@ -450,7 +466,7 @@ __device__ const float* tab_mlp_backward(const TabStep& s, const TabLds& L) {
   float* gn = L.GB;
   for (int l = 5; l >= 0; --l) {
     const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
-    const float* in = l == 0 ? L.IN0 : L.H[l - 1];
+    const float* in = l == 0 ? L.IN0 : L.H(l - 1);
     const int ldi = l == 0 ? L.IS : L.HS;
     tab_wgrad(g, L.GS, in, ldi, nin, no, L.Pl + tab_param_off(s, l), TR);
     // grad wrt this layer's input (post-activation of layer l-1)
@@ -459,7 +475,7 @@ __device__ const float* tab_mlp_backward(const TabStep& s, const TabLds& L) {
       const int act = (l - 1) == 4 ? 2 : 1;
       for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
         const int p = idx / nin, c = idx - p * nin;
-        const float h = L.H[l - 1][p * L.HS + c];
+        const float h = L.H(l - 1)[p * L.HS + c];
         gn[p * L.GS + c] *= act == 1 ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
       }
       __syncthreads();
@@ -476,7 +492,7 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
                                                       float* __restrict__ part_mix) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, true, &L, smem);
+  tab_layout(s, true, L, smem);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s);
   const int NP = tab_param_floats(s), NM = d * d + d;
   for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
@@ -553,44 +569,25 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
 
 // ---- resident backward (round 3).  As tab_bwd_kernel, with every weight matrix resident in LDS (tab_stage_resident), the
 // transposed layers as row dot products on the same copies (tab_dense_res_t: no transposed staging), and the per-workgroup
-// weight-gradient sums in private memory (TAB_PACC_MAX values per thread: thread t owns elements t, t + 256, ... of every
-// layer's [out][in + 1] block, exactly the elements it owned in the LDS version -- same sums in the same order).
-__device__ void tab_wgrad_acc(const float* g, int ldg, const float* in, int ldi, int nin, int nout, float* pacc, int kbase, int TR) {
-  int k = kbase;
-  for (int idx = threadIdx.x; idx < nout * (nin + 1); idx += blockDim.x, ++k) {
-    const int o = idx / (nin + 1), c = idx - o * (nin + 1);
-    float sacc = 0.f;
-    if (c < nin) {
-#pragma unroll 4
-      for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o] * in[p * ldi + c];
-    } else {
-#pragma unroll 4
-      for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
-    }
-    pacc[k] += sacc;
-  }
-}
-
+// weight-gradient sums in LDS as before (thread t owns elements t, t + 256, ...: no barrier around them).  The layer loops are
+// unrolled so that the LDS layout (TabLds: arrays of pointers) stays in registers: indexed with a run-time layer number it
+// lived in scratch memory, and every use of a pointer was a round trip to it -- most of a tile's time.
 __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float* __restrict__ x, const float* __restrict__ cond,
                                                           const float* __restrict__ gout, const float* __restrict__ gld,
                                                           float* __restrict__ gx, float* __restrict__ gcond,
                                                           float* __restrict__ part, float* __restrict__ part_mix) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, true, &L, smem, true);
+  tab_layout(s, true, L, smem, true);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s), YS = L.GS;   // (GY rows: the aligned stride)
   const int NP = tab_param_floats(s), NM = d * d + d;
-  float pacc[TAB_PACC_MAX];
-#pragma unroll
-  for (int i = 0; i < TAB_PACC_MAX; ++i) pacc[i] = 0.f;
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) L.PM[i] = 0.f;
   for (int i = threadIdx.x; i < TR * L.GS; i += blockDim.x) { L.GA[i] = 0.f; L.GB[i] = 0.f; L.GY[i] = 0.f; }   // pad columns finite
   tab_stage_resident(s, L);
-  int kb[7];   // first private slot of layer l (0..5), then of the channel mix
-  {
-    int t = 0;
-    for (int l = 0; l < 6; ++l) { kb[l] = t; t += (tab_layer_out(s, l) * (tab_layer_in(s, l) + 1) + 255) / 256; }
-    kb[6] = t;
-  }
+  int poff[6];   // the layers' blocks of the partial sums
+#pragma unroll
+  for (int l = 0; l < 6; ++l) poff[l] = tab_param_off(s, l);
   const int ntiles = (s.B + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * TR;
@@ -628,17 +625,18 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
     // ---- MLP backward, layers 5..0
     float* g = L.GA;
     float* gn = L.GB;
+#pragma unroll
     for (int l = 5; l >= 0; --l) {
       const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
-      const float* in = l == 0 ? L.IN0 : L.H[l - 1];
+      const float* in = l == 0 ? L.IN0 : L.H(l > 0 ? l - 1 : 0);
       const int ldi = l == 0 ? L.IS : L.HS;
-      tab_wgrad_acc(g, L.GS, in, ldi, nin, no, pacc, kb[l], TR);
-      tab_dense_res_t(g, L.GS, no, L.WR[l + 1], gn, L.GS, nin, TR);
+      tab_wgrad(g, L.GS, in, ldi, nin, no, L.Pl + poff[l], TR);
+      tab_dense_res_t(g, L.GS, no, tab_wr(s, L, l + 1), gn, L.GS, nin, TR);
       if (l > 0) {
         const int act = (l - 1) == 4 ? 2 : 1;
         for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
           const int p = idx / nin, c = idx - p * nin;
-          const float h = L.H[l - 1][p * L.HS + c];
+          const float h = L.H(l > 0 ? l - 1 : 0)[p * L.HS + c];
           gn[p * L.GS + c] *= act == 1 ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
         }
         __syncthreads();
@@ -657,8 +655,7 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
     __syncthreads();
     // ---- mix backward: partial (gWf, gcf); gx = Wf^T gy
     {
-      int k = kb[6];
-      for (int idx = threadIdx.x; idx < NM; idx += blockDim.x, ++k) {
+      for (int idx = threadIdx.x; idx < NM; idx += blockDim.x) {
         float sacc = 0.f;
         if (idx < d * d) {
           const int o = idx / d, c = idx - o * d;
@@ -669,10 +666,10 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
 #pragma unroll 4
           for (int p = 0; p < TR; ++p) sacc += L.GY[p * YS + o];
         }
-        pacc[k] += sacc;
+        L.PM[idx] += sacc;
       }
     }
-    tab_dense_res_t(L.GY, YS, d, L.WR[0], gn, L.GS, d, TR);
+    tab_dense_res_t(L.GY, YS, d, tab_wr(s, L, 0), gn, L.GS, d, TR);
     for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
       const int p = idx / d, c = idx - p * d, m = row0 + p;
       if (m < s.B) gx[(long)m * d + c] = gn[p * L.GS + c];
@@ -680,15 +677,8 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
     __syncthreads();
   }
   // the workgroup's slab of partial sums, in the layout tab_reduce_kernel / nfk_prep_bwd read
-  for (int l = 0; l < 6; ++l) {
-    const int n = tab_layer_out(s, l) * (tab_layer_in(s, l) + 1), off = tab_param_off(s, l);
-    int k = kb[l];
-    for (int idx = threadIdx.x; idx < n; idx += blockDim.x, ++k) part[(long)blockIdx.x * NP + off + idx] = pacc[k];
-  }
-  {
-    int k = kb[6];
-    for (int idx = threadIdx.x; idx < NM; idx += blockDim.x, ++k) part_mix[(long)blockIdx.x * NM + idx] = pacc[k];
-  }
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) part[(long)blockIdx.x * NP + i] = L.Pl[i];
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) part_mix[(long)blockIdx.x * NM + i] = L.PM[i];
 }
 
 // Backward of tab_inv_kernel (the reverse / sampling pass with gradients: the perceptual branch of the tabular
@@ -706,7 +696,7 @@ __global__ void __launch_bounds__(256) tab_inv_bwd_kernel(TabStep s, const float
                                                           float* __restrict__ part_mix) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, true, &L, smem);
+  tab_layout(s, true, L, smem);
   const int d = s.d, Ch = d / 2, TR = L.TR, nin0 = tab_nin0(s);
   const int NP = tab_param_floats(s), NM = d * d + d;
   for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
@@ -729,11 +719,11 @@ __global__ void __launch_bounds__(256) tab_inv_bwd_kernel(TabStep s, const float
     const float* in = L.IN0;
     int ldi = L.IS;
     for (int l = 0; l < 5; ++l) {
-      tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H[l], L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
-      in = L.H[l];
+      tab_dense(in, ldi, tab_layer_in(s, l), s.W[l], s.b[l], L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, 0, L.Wl, TR);
+      in = L.H(l);
       ldi = L.HS;
     }
-    tab_dense(L.H[4], L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
+    tab_dense(L.H(4), L.HS, s.hid, s.W[5], s.b[5], L.O, L.OS, tab_nout(s), 0, 0, L.Wl, TR);
     for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
       const int p = idx / d, c = idx - p * d;
       float v = L.Y[p * L.XS + c];
@@ -832,7 +822,8 @@ static int tab_blocks(const TabStep& s, bool bwd) {
 }
 static int tab_check(const TabStep& s, bool bwd, size_t* lds) {
   if (s.d < 2 || s.hid < 1 || s.B < 0 || s.ncond < 0) return NFK_ERR_ARG;
-  *lds = tab_layout(s, bwd, nullptr, nullptr);
+  TabLds dummy;
+  *lds = tab_layout(s, bwd, dummy, nullptr);
   return *lds > 160 * 1024 ? NFK_ERR_ARG : NFK_OK;
 }
 static int g_tab_resident = 1;   // experiment knob (NFK_TUNE_TAB_RESIDENT): 0 = the per-tile staging of rounds 1-2
@@ -842,8 +833,8 @@ static bool tab_resident_ok(const TabStep& s, bool bwd, size_t* lds) {
   if (!g_tab_resident) return false;
   const int TR = tab_rows(s.hid, s.d);
   if (TR < 4 || (TR & 3)) return false;
-  if (bwd && tab_pacc_slots(s) > TAB_PACC_MAX) return false;
-  const size_t n = tab_layout(s, bwd, nullptr, nullptr, true);
+  TabLds dummy;
+  const size_t n = tab_layout(s, bwd, dummy, nullptr, true);
   if (n > 160 * 1024 - 1024) return false;
   *lds = n;
   return true;
