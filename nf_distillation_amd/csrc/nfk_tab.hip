@@ -180,60 +180,114 @@ __device__ __forceinline__ void tab_stage_resident(const TabStep& s, const TabLd
   }
   __syncthreads();
 }
-// out[p][o] = act(sum_c in[p][c] W[o][c] + b[o]) on the resident copy (Wr = [nin][rs], br in LDS or null).  One barrier, at
-// the end (the caller's previous phase ended with one).
-__device__ void tab_dense_res(const float* in, int ldi, int nin, const float* Wr, const float* br, float* out, int ldo, int nout,
-                              int act, int TR) {
-  const int rs = tab_res_stride(nout), G4 = pad4(nout) / 4;
-  for (int t = threadIdx.x; t < TR * G4; t += blockDim.x) {
-    const int p = t / G4, o = (t - p * G4) * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+// ---- resident mode's contractions run on the matrix cores (exact-f32 v_mfma_f32_16x16x4_f32; tiles of 16 rows: TR % 16 == 0).
+// The vector-ALU loops of tab_dense read 20 bytes of LDS per four multiply-adds (one weight quad + one activation per lane); the
+// MFMA operand layout reads 8 (one weight, one activation per lane for 4 x 16 x 16 / 64 = 16 multiply-adds per lane).
+// Operand a of mfma(a, b, acc): lane l holds a[row = l & 15][k = l >> 4]; b likewise; acc[r] = out[a row 4 (l >> 4) + r][b row l & 15].
+// Here a = the weight side (16 output columns), b = the row side (16 rows of the tile).  A wave takes whole 16 x 16 tiles.
+typedef float tab_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tab_dense_mfma(const float* in, int ldi, int nin, const float* Wr, const float* br, float* out,
+                                               int ldo, int nout, int act, int TR) {
+  const int rs = tab_res_stride(nout), wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const int MT = TR >> 4, NT = (nout + 15) >> 4;
+  for (int t = wave; t < MT * NT; t += 4) {
+    const int mt = t % MT, nt = t / MT;
+    const int p = mt * 16 + r16, oa = nt * 16 + r16, ob = nt * 16 + 4 * q;
+    tab_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (br)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (o + r < nout) acc[r] = br[o + r];
-    const float* xr = in + p * ldi;
-#pragma unroll 4
-    for (int c = 0; c < nin; ++c) {
-      const float xv = xr[c];
-      const f32x4 w = *reinterpret_cast<const f32x4*>(Wr + c * rs + o);
+      for (int r = 0; r < 4; ++r) if (ob + r < nout) acc[r] = br[ob + r];
+    const float* wp = Wr + (oa < nout ? oa : 0);
+    const float* xp = in + p * ldi;
+    const bool wok = oa < nout;
+    for (int k0 = 0; k0 < nin; k0 += 16) {   // four k-steps per trip: eight loads in flight, then four MFMAs
+      float a[4], b[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] += w[r] * xv;
+      for (int j = 0; j < 4; ++j) {
+        const int c = k0 + 4 * j + q;
+        const bool ok = c < nin;
+        a[j] = (ok && wok) ? wp[c * rs] : 0.f;
+        b[j] = ok ? xp[c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (o + r < nout) {
+      if (ob + r < nout) {
         float v = acc[r];
         if (act == 1) v = fmaxf(v, 0.f);
         else if (act == 2) v = tanhf(v);
-        out[p * ldo + o + r] = v;
+        out[p * ldo + ob + r] = v;
       }
   }
   __syncthreads();
 }
-// The transposed layer on the SAME resident copy:  out[p][c] = sum_o g[p][o] W[o][c] = dot(g[p][:], Wr[c][:])  -- a weight row
-// (contiguous over o, 16-byte pieces) against FOUR gradient rows per thread (g rows 16-byte aligned: ldg % 4 == 0, TR % 4 == 0).
-// nred = the forward layer's outputs (reduction length), nout_t = its inputs.  Pad columns of Wr are zero; g's pad entries are
-// kept finite by the callers (zeroed once per workgroup).
-__device__ void tab_dense_res_t(const float* g, int ldg, int nred, const float* Wr, float* out, int ldo, int nout_t, int TR) {
-  const int rs = tab_res_stride(nred), n4 = pad4(nred), PG = TR / 4;
-  for (int t = threadIdx.x; t < nout_t * PG; t += blockDim.x) {
-    const int pg = t / nout_t, c = t - pg * nout_t;
-    const float* wrow = Wr + c * rs;
-    const float* g0 = g + (pg * 4) * ldg;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int o = 0; o < n4; o += 4) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + o);
+// out[p][c] = sum_o g[p][o] Wr[c][o]  (o < nred; c < nout_t): a = weight rows c, b = gradient rows p, k = o
+__device__ __forceinline__ void tab_dense_t_mfma(const float* g, int ldg, int nred, const float* Wr, float* out, int ldo,
+                                                 int nout_t, int TR) {
+  const int rs = tab_res_stride(nred), wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const int MT = TR >> 4, NT = (nout_t + 15) >> 4;
+  for (int t = wave; t < MT * NT; t += 4) {
+    const int mt = t % MT, nt = t / MT;
+    const int p = mt * 16 + r16, ca = nt * 16 + r16, cb = nt * 16 + 4 * q;
+    tab_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool wok = ca < nout_t;
+    const float* wp = Wr + (wok ? ca : 0) * rs;
+    const float* gp = g + p * ldg;
+    for (int k0 = 0; k0 < nred; k0 += 16) {
+      float a[4], b[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g0 + r * ldg + o);
-        acc[r] += (w[0] * gv[0] + w[1] * gv[1]) + (w[2] * gv[2] + w[3] * gv[3]);
+      for (int j = 0; j < 4; ++j) {
+        const int o = k0 + 4 * j + q;
+        const bool ok = o < nred;
+        a[j] = (ok && wok) ? wp[o] : 0.f;
+        b[j] = ok ? gp[o] : 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(pg * 4 + r) * ldo + c] = acc[r];
+    for (int r = 0; r < 4; ++r)
+      if (cb + r < nout_t) out[p * ldo + cb + r] = acc[r];
   }
   __syncthreads();
+}
+// P[o * ldp + c] += sum_p g[p][o] in[p][c];  Pb[o * bstride] += sum_p g[p][o].  a = gradient columns o, b = input columns c,
+// k = the tile's rows.  An element of P always belongs to the same lane (no barrier around the sums); no barrier inside.
+__device__ __forceinline__ void tab_wgrad_mfma(const float* g, int ldg, const float* in, int ldi, int nin, int nout, float* P,
+                                               int ldp, float* Pb, int bstride, int TR) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const int OT = (nout + 15) >> 4, CT = (nin + 15) >> 4;
+  for (int t = wave; t < OT * CT; t += 4) {
+    const int ct = t % CT, ot = t / CT;
+    const int oa = ot * 16 + r16, cb = ct * 16 + r16, ob = ot * 16 + 4 * q;
+    const bool aok = oa < nout, bok = cb < nin;
+    const float* gp = g + (aok ? oa : 0);
+    const float* ip = in + (bok ? cb : 0);
+    tab_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < TR; k0 += 16) {   // (TR % 16 == 0)
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = k0 + 4 * j + q;
+        a[j] = aok ? gp[p * ldg] : 0.f;
+        b[j] = bok ? ip[p * ldi] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    if (bok)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ob + r < nout) P[(ob + r) * ldp + cb] += acc[r];
+  }
+  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+    float sacc = 0.f;
+#pragma unroll 4
+    for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
+    Pb[o * bstride] += sacc;
+  }
 }
 
 // Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
@@ -243,7 +297,7 @@ __device__ __forceinline__ void tab_forward_tile(const TabStep& s, const TabLds&
     const int p = idx / d, c = idx - p * d, m = row0 + p;
     L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
   }
-  if (L.res) { __syncthreads(); tab_dense_res(L.X, L.XS, d, tab_wr(s, L, 0), tab_br(s, L, 0), L.Y, L.XS, d, 0, TR); }
+  if (L.res) { __syncthreads(); tab_dense_mfma(L.X, L.XS, d, tab_wr(s, L, 0), tab_br(s, L, 0), L.Y, L.XS, d, 0, TR); }
   else tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
   const int nin0 = tab_nin0(s), nf = tab_nfeat(s);
   for (int idx = threadIdx.x; idx < TR * nin0; idx += blockDim.x) {
@@ -259,11 +313,11 @@ __device__ __forceinline__ void tab_forward_tile(const TabStep& s, const TabLds&
     __syncthreads();
 #pragma unroll
     for (int l = 0; l < 5; ++l) {
-      tab_dense_res(in, ldi, tab_layer_in(s, l), tab_wr(s, L, l + 1), tab_br(s, L, l + 1), L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, TR);
+      tab_dense_mfma(in, ldi, tab_layer_in(s, l), tab_wr(s, L, l + 1), tab_br(s, L, l + 1), L.H(l), L.HS, s.hid, l == 4 ? 2 : 1, TR);
       in = L.H(l);
       ldi = L.HS;
     }
-    tab_dense_res(L.H(4), L.HS, s.hid, tab_wr(s, L, 6), tab_br(s, L, 6), L.O, L.OS, tab_nout(s), 0, TR);
+    tab_dense_mfma(L.H(4), L.HS, s.hid, tab_wr(s, L, 6), tab_br(s, L, 6), L.O, L.OS, tab_nout(s), 0, TR);
     return;
   }
   for (int l = 0; l < 5; ++l) {
@@ -630,8 +684,8 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
       const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
       const float* in = l == 0 ? L.IN0 : L.H(l > 0 ? l - 1 : 0);
       const int ldi = l == 0 ? L.IS : L.HS;
-      tab_wgrad(g, L.GS, in, ldi, nin, no, L.Pl + poff[l], TR);
-      tab_dense_res_t(g, L.GS, no, tab_wr(s, L, l + 1), gn, L.GS, nin, TR);
+      tab_wgrad_mfma(g, L.GS, in, ldi, nin, no, L.Pl + poff[l], nin + 1, L.Pl + poff[l] + nin, nin + 1, TR);
+      tab_dense_t_mfma(g, L.GS, no, tab_wr(s, L, l + 1), gn, L.GS, nin, TR);
       if (l > 0) {
         const int act = (l - 1) == 4 ? 2 : 1;
         for (int idx = threadIdx.x; idx < TR * nin; idx += blockDim.x) {
@@ -654,22 +708,8 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
     }
     __syncthreads();
     // ---- mix backward: partial (gWf, gcf); gx = Wf^T gy
-    {
-      for (int idx = threadIdx.x; idx < NM; idx += blockDim.x) {
-        float sacc = 0.f;
-        if (idx < d * d) {
-          const int o = idx / d, c = idx - o * d;
-#pragma unroll 4
-          for (int p = 0; p < TR; ++p) sacc += L.GY[p * YS + o] * L.X[p * L.XS + c];
-        } else {
-          const int o = idx - d * d;
-#pragma unroll 4
-          for (int p = 0; p < TR; ++p) sacc += L.GY[p * YS + o];
-        }
-        L.PM[idx] += sacc;
-      }
-    }
-    tab_dense_res_t(L.GY, YS, d, tab_wr(s, L, 0), gn, L.GS, d, TR);
+    tab_wgrad_mfma(L.GY, YS, L.X, L.XS, d, d, L.PM, d, L.PM + d * d, 1, TR);
+    tab_dense_t_mfma(L.GY, YS, d, tab_wr(s, L, 0), gn, L.GS, d, TR);
     for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
       const int p = idx / d, c = idx - p * d, m = row0 + p;
       if (m < s.B) gx[(long)m * d + c] = gn[p * L.GS + c];
@@ -832,7 +872,7 @@ static int g_tab_resident = 1;   // experiment knob (NFK_TUNE_TAB_RESIDENT): 0 =
 static bool tab_resident_ok(const TabStep& s, bool bwd, size_t* lds) {
   if (!g_tab_resident) return false;
   const int TR = tab_rows(s.hid, s.d);
-  if (TR < 4 || (TR & 3)) return false;
+  if (TR < 16 || (TR & 15)) return false;   // (the MFMA tiles: 16 rows)
   TabLds dummy;
   const size_t n = tab_layout(s, bwd, dummy, nullptr, true);
   if (n > 160 * 1024 - 1024) return false;
