@@ -138,7 +138,7 @@ void nfk_tune(int knob, int value) {
     case NFK_TUNE_WGRAD_HALO_MAX_SPLITS: set_tuning_bf16(3000 + value); break;
     case NFK_TUNE_RUN_HALF_TILES: fused2_set_half_tiles(value); fusedb_set_small_tiles(value); break;
     case NFK_TUNE_SPLIT_FUSED: g_split_fused = value & 1; break;
-    case NFK_TUNE_TAB_RESIDENT: tab_set_resident(value & 1); break;
+    case NFK_TUNE_TAB_RESIDENT: tab_set_resident(value); break;
     default: break;
   }
 }

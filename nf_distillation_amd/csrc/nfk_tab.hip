@@ -73,10 +73,10 @@ __host__ __device__ static inline float* tab_br(const TabStep& s, const TabLds& 
   return L.WR0 + tab_wr_off(s, k) + pad4(tab_w_in(s, k) * tab_res_stride(tab_w_out(s, k)));
 }
 
-__host__ __device__ __attribute__((always_inline)) static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds& Lr, float* base, bool res = false) {
+__host__ __device__ __attribute__((always_inline)) static inline size_t tab_layout(const TabStep& s, bool bwd, TabLds& Lr, float* base, bool res = false, int tr = 0) {
   TabLds* const L = &Lr;   // (a reference: a null test on a private-memory address pins the struct in scratch memory)
   const int d = s.d, hid = s.hid, nout = tab_nout(s), nin0 = tab_nin0(s);
-  const int TR = tab_rows(hid, d);
+  const int TR = tr > 0 ? tr : tab_rows(hid, d);   // (tr: the resident forward's taller tiles)
   int mx = d > hid ? d : hid;
   if (nout > mx) mx = nout;
   if (nin0 > mx) mx = nin0;
@@ -291,12 +291,15 @@ __device__ __forceinline__ void tab_wgrad_mfma(const float* g, int ldg, const fl
 }
 
 // Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
-__device__ __forceinline__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0) {
+// `staged`: the caller has put the tile's rows into L.X already (the resident forward requests them one tile ahead)
+__device__ __forceinline__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0,
+                                                 bool staged = false) {
   const int d = s.d, TR = L.TR;
-  for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
-    const int p = idx / d, c = idx - p * d, m = row0 + p;
-    L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
-  }
+  if (!staged)
+    for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
+      const int p = idx / d, c = idx - p * d, m = row0 + p;
+      L.X[p * L.XS + c] = m < s.B ? x[(long)m * d + c] : 0.f;
+    }
   if (L.res) { __syncthreads(); tab_dense_mfma(L.X, L.XS, d, tab_wr(s, L, 0), tab_br(s, L, 0), L.Y, L.XS, d, 0, TR); }
   else tab_dense(L.X, L.XS, d, s.Wf, s.cf, L.Y, L.XS, d, 0, 0, L.Wl, TR);
   const int nin0 = tab_nin0(s), nf = tab_nfeat(s);
@@ -333,13 +336,35 @@ __global__ void __launch_bounds__(256) tab_fwd_kernel(TabStep s, const float* __
                                                       float* __restrict__ zout, float* __restrict__ ld_out, int res) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, false, L, smem, res != 0);
+  tab_layout(s, false, L, smem, res != 0, res);   // res = rows per tile in resident mode
   if (res) tab_stage_resident(s, L);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR;
   const int ntiles = (s.B + TR - 1) / TR;
+  // resident mode: the NEXT tile's rows are requested (into registers) before this tile's chain of short phases starts
+  constexpr int XPF = 4;
+  const bool pf = res != 0 && TR * d <= XPF * 256;
+  float xpf[XPF];
+  auto request = [&](int tile) {
+#pragma unroll
+    for (int e = 0; e < XPF; ++e) {
+      const int idx = threadIdx.x + e * 256;
+      const int p = idx / d, c = idx - p * d, m = tile * TR + p;
+      xpf[e] = (idx < TR * d && tile < ntiles && m < s.B) ? x[(long)m * d + c] : 0.f;
+    }
+  };
+  if (pf) request(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * TR;
-    tab_forward_tile(s, L, x, cond, row0);
+    if (pf) {
+#pragma unroll
+      for (int e = 0; e < XPF; ++e) {
+        const int idx = threadIdx.x + e * 256;
+        const int p = idx / d, c = idx - p * d;
+        if (idx < TR * d) L.X[p * L.XS + c] = xpf[e];
+      }
+      request(tile + gridDim.x);
+    }
+    tab_forward_tile(s, L, x, cond, row0, pf);
     if (s.made) {   // u = (y - mu) exp(-alpha) on every feature; log-det terms -alpha into X
       for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
         const int p = idx / d, j = idx - p * d, m = row0 + p;
@@ -866,6 +891,7 @@ static int tab_check(const TabStep& s, bool bwd, size_t* lds) {
   *lds = tab_layout(s, bwd, dummy, nullptr);
   return *lds > 160 * 1024 ? NFK_ERR_ARG : NFK_OK;
 }
+static int g_tab_tall_min_tiles = 512;   // taller forward tiles only when this many of them exist
 static int g_tab_resident = 1;   // experiment knob (NFK_TUNE_TAB_RESIDENT): 0 = the per-tile staging of rounds 1-2
 // resident mode: every weight matrix in LDS for the life of the workgroup -- if the layout fits, the tile has a multiple of
 // four rows (the transposed layers take four gradient rows per thread) and, backward, the private sums fit their slots
@@ -879,7 +905,10 @@ static bool tab_resident_ok(const TabStep& s, bool bwd, size_t* lds) {
   *lds = n;
   return true;
 }
-void tab_set_resident(int on) { g_tab_resident = on; }
+void tab_set_resident(int on) {   // bit 0: resident mode; bits 8..: (experiment) least number of tall tiles, 0 = default
+  g_tab_resident = on & 1;
+  g_tab_tall_min_tiles = (on >> 8) > 0 ? (on >> 8) : 512;
+}
 
 }  // namespace nfk
 
@@ -897,16 +926,28 @@ int nfk_tab_fwd(const nfk_tab_step* s, const float* x, const float* cond, const 
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   size_t lds_r;
-  const bool res = tab_resident_ok(*s, false, &lds_r);
+  int res = tab_resident_ok(*s, false, &lds_r) ? tab_rows(s->hid, s->d) : 0;
   int nb = tab_blocks(*s, false);
   if (res) {   // a workgroup stages the weights once and then walks its tiles: as many as fit the chip, no more
+    // taller tiles (a tile's phases are chains of short dependent steps: twice the rows cost little more) while there are
+    // enough tiles left for every CU
+    for (int tr = 64; tr > res; tr >>= 1) {
+      TabLds dummy;
+      const size_t n = tab_layout(*s, false, dummy, nullptr, true, tr);
+      // ... and only where they do not cost a co-resident workgroup (two per CU overlap each other's waits)
+      const int per_base = (int)((160 * 1024) / (lds_r + 1024)), per_tr = (int)((160 * 1024) / (n + 1024));
+      if (n <= 160 * 1024 - 1024 && ceil_div(s->B, tr) >= g_tab_tall_min_tiles && per_tr >= (per_base < 2 ? per_base : 2)) {
+        res = tr; lds_r = n; break;
+      }
+    }
     lds = lds_r;
+    nb = ceil_div(s->B, res);
     const int per_cu = (int)((160 * 1024) / (lds_r + 1024));
     const int cap = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (nb > cap) nb = cap;
   }
   hipLaunchKernelGGL(tab_fwd_kernel, dim3(nb), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                     *s, x, cond, ld_in, zout, ld_out, res ? 1 : 0);
+                     *s, x, cond, ld_in, zout, ld_out, res);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }
