@@ -104,7 +104,7 @@ __host__ __device__ __attribute__((always_inline)) static inline size_t tab_layo
   size_t oGA = 0, oGB = 0, oGY = 0, oP = 0, oPM = 0;
   if (bwd) {
     oGA = take((size_t)TR * GS); oGB = take((size_t)TR * GS); oGY = take((size_t)TR * (res ? GS : XS));
-    oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d);
+    if (!res) { oP = take((size_t)tab_param_floats(s)); oPM = take((size_t)d * d + d); }   // (resident: in registers)
   }
   size_t oWR = 0;
   if (res) {
@@ -253,44 +253,64 @@ __device__ __forceinline__ void tab_dense_t_mfma(const float* g, int ldg, int nr
   }
   __syncthreads();
 }
-// P[o * ldp + c] += sum_p g[p][o] in[p][c];  Pb[o * bstride] += sum_p g[p][o].  a = gradient columns o, b = input columns c,
-// k = the tile's rows.  An element of P always belongs to the same lane (no barrier around the sums); no barrier inside.
-__device__ __forceinline__ void tab_wgrad_mfma(const float* g, int ldg, const float* in, int ldi, int nin, int nout, float* P,
-                                               int ldp, float* Pb, int bstride, int TR) {
+// acc[j] (tile t = wave + 4 j of the layer's OT x CT tiles of 16 x 16) += sum_p g[p][o] in[p][c];  bacc += sum_p g[p][o = thread].
+// a = gradient columns o, b = input columns c, k = the tile's rows.  The sums stay in registers for the life of the
+// workgroup (at most TAB_WG_TILES tiles per wave and layer: tab_resident_ok), written out once by tab_wgrad_store.
+constexpr int TAB_WG_TILES = 4;
+__device__ __forceinline__ void tab_wgrad_mfma(const float* g, int ldg, const float* in, int ldi, int nin, int nout,
+                                               tab_f32x4 (&acc)[TAB_WG_TILES], float& bacc, int TR) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
   const int OT = (nout + 15) >> 4, CT = (nin + 15) >> 4;
-  for (int t = wave; t < OT * CT; t += 4) {
-    const int ct = t % CT, ot = t / CT;
-    const int oa = ot * 16 + r16, cb = ct * 16 + r16, ob = ot * 16 + 4 * q;
-    const bool aok = oa < nout, bok = cb < nin;
-    const float* gp = g + (aok ? oa : 0);
-    const float* ip = in + (bok ? cb : 0);
-    tab_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < TR; k0 += 16) {   // (TR % 16 == 0)
-      float a[4], b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int p = k0 + 4 * j + q;
-        a[j] = aok ? gp[p * ldg] : 0.f;
-        b[j] = bok ? ip[p * ldi] : 0.f;
+  for (int j = 0; j < TAB_WG_TILES; ++j) {
+    const int t = wave + 4 * j;
+    if (t < OT * CT) {
+      const int ct = t % CT, ot = t / CT;
+      const int oa = ot * 16 + r16, cb = ct * 16 + r16;
+      const bool aok = oa < nout, bok = cb < nin;
+      const float* gp = g + (aok ? oa : 0);
+      const float* ip = in + (bok ? cb : 0);
+      tab_f32x4 v = acc[j];
+      for (int k0 = 0; k0 < TR; k0 += 16) {   // (TR % 16 == 0)
+        float a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int p = k0 + 4 * e + q;
+          a[e] = aok ? gp[p * ldg] : 0.f;
+          b[e] = bok ? ip[p * ldi] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], v, 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+      acc[j] = v;
     }
-    if (bok)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (ob + r < nout) P[(ob + r) * ldp + cb] += acc[r];
   }
-  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+  if ((int)threadIdx.x < nout) {
     float sacc = 0.f;
 #pragma unroll 4
-    for (int p = 0; p < TR; ++p) sacc += g[p * ldg + o];
-    Pb[o * bstride] += sacc;
+    for (int p = 0; p < TR; ++p) sacc += g[p * ldg + threadIdx.x];
+    bacc += sacc;
   }
 }
+// the sums of one layer -> the workgroup's slab:  P[o * ldp + c],  Pb[o * bstride]
+__device__ __forceinline__ void tab_wgrad_store(int nin, int nout, const tab_f32x4 (&acc)[TAB_WG_TILES], float bacc, float* P,
+                                                int ldp, float* Pb, int bstride) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const int OT = (nout + 15) >> 4, CT = (nin + 15) >> 4;
+#pragma unroll
+  for (int j = 0; j < TAB_WG_TILES; ++j) {
+    const int t = wave + 4 * j;
+    if (t < OT * CT) {
+      const int ct = t % CT, ot = t / CT, cb = ct * 16 + r16, ob = ot * 16 + 4 * q;
+      if (cb < nin)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < nout) P[(ob + r) * ldp + cb] = acc[j][r];
+    }
+  }
+  if ((int)threadIdx.x < nout) Pb[threadIdx.x * bstride] = bacc;
+}
 
-// Load X tile, mix (y = Wf x + cf), build the first-layer input, run the MLP.  Leaves X, Y, IN0, H[0..4], O in LDS.
 // `staged`: the caller has put the tile's rows into L.X already (the resident forward requests them one tile ahead)
 __device__ __forceinline__ void tab_forward_tile(const TabStep& s, const TabLds& L, const float* x, const float* cond, int row0,
                                                  bool staged = false) {
@@ -654,14 +674,20 @@ __global__ void __launch_bounds__(256) tab_bwd_kernel(TabStep s, const float* __
 __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float* __restrict__ x, const float* __restrict__ cond,
                                                           const float* __restrict__ gout, const float* __restrict__ gld,
                                                           float* __restrict__ gx, float* __restrict__ gcond,
-                                                          float* __restrict__ part, float* __restrict__ part_mix) {
+                                                          float* __restrict__ part, float* __restrict__ part_mix, int tr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TabLds L;
-  tab_layout(s, true, L, smem, true);
+  tab_layout(s, true, L, smem, true, tr);
   const int d = s.d, Ch = d / 2, C2 = d - Ch, TR = L.TR, nin0 = tab_nin0(s), YS = L.GS;   // (GY rows: the aligned stride)
   const int NP = tab_param_floats(s), NM = d * d + d;
-  for (int i = threadIdx.x; i < NP; i += blockDim.x) L.Pl[i] = 0.f;
-  for (int i = threadIdx.x; i < NM; i += blockDim.x) L.PM[i] = 0.f;
+  tab_f32x4 wacc[7][TAB_WG_TILES];   // weight-gradient sums: layers 0..5, then the channel mix
+  float bacc[7];
+#pragma unroll
+  for (int l = 0; l < 7; ++l) {
+    bacc[l] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TAB_WG_TILES; ++j) wacc[l][j] = tab_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int i = threadIdx.x; i < TR * L.GS; i += blockDim.x) { L.GA[i] = 0.f; L.GB[i] = 0.f; L.GY[i] = 0.f; }   // pad columns finite
   tab_stage_resident(s, L);
   int poff[6];   // the layers' blocks of the partial sums
@@ -709,7 +735,7 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
       const int nin = tab_layer_in(s, l), no = tab_layer_out(s, l);
       const float* in = l == 0 ? L.IN0 : L.H(l > 0 ? l - 1 : 0);
       const int ldi = l == 0 ? L.IS : L.HS;
-      tab_wgrad_mfma(g, L.GS, in, ldi, nin, no, L.Pl + poff[l], nin + 1, L.Pl + poff[l] + nin, nin + 1, TR);
+      tab_wgrad_mfma(g, L.GS, in, ldi, nin, no, wacc[l], bacc[l], TR);
       tab_dense_t_mfma(g, L.GS, no, tab_wr(s, L, l + 1), gn, L.GS, nin, TR);
       if (l > 0) {
         const int act = (l - 1) == 4 ? 2 : 1;
@@ -733,7 +759,7 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
     }
     __syncthreads();
     // ---- mix backward: partial (gWf, gcf); gx = Wf^T gy
-    tab_wgrad_mfma(L.GY, YS, L.X, L.XS, d, d, L.PM, d, L.PM + d * d, 1, TR);
+    tab_wgrad_mfma(L.GY, YS, L.X, L.XS, d, d, wacc[6], bacc[6], TR);
     tab_dense_t_mfma(L.GY, YS, d, tab_wr(s, L, 0), gn, L.GS, d, TR);
     for (int idx = threadIdx.x; idx < TR * d; idx += blockDim.x) {
       const int p = idx / d, c = idx - p * d, m = row0 + p;
@@ -742,8 +768,14 @@ __global__ void __launch_bounds__(256) tab_bwd_res_kernel(TabStep s, const float
     __syncthreads();
   }
   // the workgroup's slab of partial sums, in the layout tab_reduce_kernel / nfk_prep_bwd read
-  for (int i = threadIdx.x; i < NP; i += blockDim.x) part[(long)blockIdx.x * NP + i] = L.Pl[i];
-  for (int i = threadIdx.x; i < NM; i += blockDim.x) part_mix[(long)blockIdx.x * NM + i] = L.PM[i];
+  float* pb = part + (long)blockIdx.x * NP;
+#pragma unroll
+  for (int l = 0; l < 6; ++l) {
+    const int nin = tab_layer_in(s, l);
+    tab_wgrad_store(nin, tab_layer_out(s, l), wacc[l], bacc[l], pb + poff[l], nin + 1, pb + poff[l] + nin, nin + 1);
+  }
+  float* pm = part_mix + (long)blockIdx.x * NM;
+  tab_wgrad_store(d, d, wacc[6], bacc[6], pm, d, pm + d * d, 1);
 }
 
 // Backward of tab_inv_kernel (the reverse / sampling pass with gradients: the perceptual branch of the tabular
@@ -899,6 +931,12 @@ static bool tab_resident_ok(const TabStep& s, bool bwd, size_t* lds) {
   if (!g_tab_resident) return false;
   const int TR = tab_rows(s.hid, s.d);
   if (TR < 16 || (TR & 15)) return false;   // (the MFMA tiles: 16 rows)
+  if (bwd) {   // the weight-gradient sums of a layer: at most TAB_WG_TILES 16 x 16 tiles per wave, in registers
+    if (((s.d + 15) / 16) * ((s.d + 15) / 16) > 4 * TAB_WG_TILES || s.d > 256) return false;
+    for (int l = 0; l < 6; ++l)
+      if (((tab_layer_out(s, l) + 15) / 16) * ((tab_layer_in(s, l) + 15) / 16) > 4 * TAB_WG_TILES || tab_layer_out(s, l) > 256)
+        return false;
+  }
   TabLds dummy;
   const size_t n = tab_layout(s, bwd, dummy, nullptr, true);
   if (n > 160 * 1024 - 1024) return false;
@@ -977,7 +1015,15 @@ int nfk_tab_bwd(const nfk_tab_step* s, const nfk_tab_grads* g, const float* x, c
   if (tab_resident_ok(*s, true, &lds_r)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tab_bwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    hipLaunchKernelGGL(tab_bwd_res_kernel, dim3(nb), dim3(256), lds_r, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
+    // taller tiles while every workgroup of the (unchanged) grid still gets one: the slab count nb is the caller's
+    int tr = tab_rows(s->hid, s->d);
+    for (int t = 64; t > tr; t >>= 1) {
+      TabLds dummy;
+      const size_t n = tab_layout(*s, true, dummy, nullptr, true, t);
+      if (n <= 160 * 1024 - 1024 && ceil_div(s->B, t) >= nb && ceil_div(s->B, t) >= g_tab_tall_min_tiles / 2) { tr = t; lds_r = n; break; }
+    }
+    hipLaunchKernelGGL(tab_bwd_res_kernel, dim3(nb), dim3(256), lds_r, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix,
+                       tr);
   } else {
     hipLaunchKernelGGL(tab_bwd_kernel, dim3(nb), dim3(256), lds, st, *s, x, cond, g_out, g_ld, g_x, g_cond, part, part_mix);
   }
