@@ -1,3 +1,4 @@
+"""One row of tools/config_bench.py (for kernel traces): python tools/config_case.py {distill|c4}"""
 import sys; sys.path[:0]=["/root/repo","/root/repo/tools","/root/repo/tests"]
 import torch, config_bench as CB
 dev=torch.device("cuda",0)

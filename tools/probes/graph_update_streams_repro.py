@@ -1,3 +1,8 @@
+"""Reproducer of the HIP runtime fault recorded in DESIGN.md section 5: a captured graph with three branches (teacher || student ||
+the auxiliary stream's level weight gradients, engine.level_wgrad_aux = True) segfaults inside hip::Graph::UpdateStreams at its
+first hipGraphLaunch when earlier graphs that used the same auxiliary stream were captured AND destroyed in this process.
+    python tools/probes/graph_update_streams_repro.py all      (on a GPU box; `rocgdb -x tools/probes/graph_update_streams_gdb.txt`)
+Not part of any test: the product keeps the option off by default and bench.py keeps its graphs alive."""
 import sys, os, faulthandler
 faulthandler.enable()
 ROOT = "/root/repo"

@@ -1,3 +1,4 @@
+"""The 1-D rows of tools/config_bench.py alone (training step under hipGraph replay, eager forward)."""
 import sys; sys.path[:0]=["/root/repo","/root/repo/tools","/root/repo/tests"]
 import torch, config_bench as CB
 dev=torch.device("cuda",0)
