@@ -116,8 +116,8 @@ __device__ __forceinline__ int fb_img_off(int px, int slot) {
 // The arithmetic per element is that of chanmix_body / coupling_bwd_kernel (nfk_tail.h, nfk_flow.hip).
 template <int MT32, int NTD, int K3M, int MO = 4, bool LV = false, bool MULTI = false>
 __global__ void __launch_bounds__(256) fusedb_step_bwd_kernel(FBArgs a) {
-  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MT32 == 1) || (MO == 2 && MT32 == 3 && !MULTI),
-                "small tiles: whole tiny images, or one 32-pixel image row (+ halo rows) per tile");
+  static_assert(MO == 4 || ((MO == 2 || MO == 1) && MT32 == 1) || (MO == 2 && (MT32 == 3 || MT32 == 2) && !MULTI),
+                "small tiles: whole tiny images, or 32 pixels of image rows (+ halo rows) per tile");
   static_assert(!MULTI || LV, "runs of steps exist in level mode only");
   typedef const __attribute__((address_space(4))) nfk_step2d CStep;        // scalar (constant-memory) loads
   typedef const __attribute__((address_space(4))) nfk_level_grads CGrads;
@@ -881,12 +881,17 @@ static bool fb_pick(const nfk_step2d& s, FBArgs* a) {
   else if (s.W <= 64 && s.H % (64 / s.W) == 0 && 64 / s.W < s.H) {
     a->R = 64 / s.W; a->TS = 1; a->halo = 1;
     if (a->R == 2 && s.W == 32 && fb_geom(s, 2, 1, 1).MT32 > 3) a->R = 1;   // rows of 32 pixels: one row per tile (nfk_fused2.hip)
+    // 16-pixel rows whose four-row tile (96-pixel h-region) does not fit LDS (16 x 16 x 24, level 2 of 64 x 64 images:
+    // 164 KB): two rows per tile, 32 output pixels, 64 computed
+    else if (a->R == 4 && s.W == 16 && fb_geom(s, 4, 1, 1).total > 160 * 1024 - 512 - 8 * 1024) a->R = 2;
   }
   else return false;
   const FBGeom g = fb_geom(s, a->R, a->TS, a->halo);
   if (g.MT32 != 2 && g.MT32 != 3) return false;
   const bool row32 = a->TS == 1 && a->R * s.W == 32;
-  if (a->TS == 1 && a->R * s.W != 64 && !(row32 && g.MT32 == 3 && g.NTD == 1 && g.K3M == 8)) return false;
+  if (a->TS == 1 && a->R * s.W != 64 &&
+      !(row32 && ((g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) || (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16))))
+    return false;
   if (g.total > 160 * 1024 - 512) return false;
   if ((size_t)4 * 64 * g.NTD * 16 * 4 > (size_t)g.MT32 * 32 * 1024) return false;   // R3 lives in the image
   if (a->TS * g.RZ * s.W * s.Cout > 12 * 256) return false;                          // prologue register slots
@@ -955,7 +960,8 @@ int fusedb_launch(const FusedBwdCall& c, hipStream_t st) {
       return rc;
     }
   }
-  if (a.TS == 1 && a.R * s.W == 32) rc = fb_launch_t<3, 1, 8, 2>(a, g, grid, st);
+  if (a.TS == 1 && a.R * s.W == 32 && g.MT32 == 2) rc = fb_launch_t<2, 1, 16, 2>(a, g, grid, st);
+  else if (a.TS == 1 && a.R * s.W == 32) rc = fb_launch_t<3, 1, 8, 2>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 8) rc = fb_launch_t<3, 1, 8>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 16) rc = fb_launch_t<3, 1, 16>(a, g, grid, st);
   else if (g.MT32 == 3 && g.NTD == 1 && g.K3M == 4) rc = fb_launch_t<3, 1, 4>(a, g, grid, st);
@@ -1013,6 +1019,7 @@ static int fb_level_dispatch(const FBArgs& a, const FBGeom& g, int mo, int grid,
   if (mo == 1 && g.MT32 == 1 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<1, 2, 28, 1, true, MULTI>(a, g, grid, st);
   if (mo == 2 && g.MT32 == 1 && g.NTD == 2 && g.K3M == 28) return fb_launch_t<1, 2, 28, 2, true, MULTI>(a, g, grid, st);
   if (mo == 2 && g.MT32 == 3 && g.NTD == 1 && g.K3M == 8 && !MULTI) return fb_launch_t<3, 1, 8, 2, true, false>(a, g, grid, st);
+  if (mo == 2 && g.MT32 == 2 && g.NTD == 1 && g.K3M == 16 && !MULTI) return fb_launch_t<2, 1, 16, 2, true, false>(a, g, grid, st);
   if (mo != 4) return NFK_ERR_ARG;
   if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 8) return fb_launch_t<2, 1, 8, 4, true, MULTI>(a, g, grid, st);
   if (g.MT32 == 2 && g.NTD == 1 && g.K3M == 16) return fb_launch_t<2, 1, 16, 4, true, MULTI>(a, g, grid, st);

@@ -225,10 +225,10 @@ def test_fused_step_on_32_pixel_rows():
     outs, bpd16, _ = model(x.clone().cuda(), None, noise=noise.cuda())
     steps = [r for r in model.flow.engine().state["recs"] if r.kind == "step"]
     assert all(capi.lib().nfk_step2d_fused_tiles(ctypes.byref(r.cs)) > 0 for r in steps)          # level 1 included
-    # backward: level 1 (32 x 32 x 12) on the fused kernels; level 2 here (16 x 16 x 24: a 96-pixel h-region with 256-wide
-    # im2col rows, 164 KB of LDS) stays on the per-conv launches
-    assert all(capi.lib().nfk_step2d_fused_bwd_ok(ctypes.byref(r.cs)) for r in steps if r.W == 32)
-    assert capi.lib().nfk_level_bwd_ok(ctypes.byref(steps[0].cs)) == 1
+    # backward: level 1 (32 x 32 x 12) on the fused kernels, one image row per tile; level 2 here (16 x 16 x 24: with four
+    # rows per tile a 96-pixel h-region with 256-wide im2col rows, 164 KB of LDS) on tiles of two rows
+    assert all(capi.lib().nfk_step2d_fused_bwd_ok(ctypes.byref(r.cs)) for r in steps)
+    assert all(capi.lib().nfk_level_bwd_ok(ctypes.byref(r.cs)) == 1 for r in steps)
     assert capi.lib().nfk_step2d_fused_tiles(ctypes.byref(steps[0].cs)) == 32                       # one tile per image row
     # the level form of the backward against the per-step calls on this geometry
     grads = {}

@@ -17,7 +17,8 @@ from param_util import synthetic_images  # noqa: E402
 
 
 def run(batch, pipelined, steps, warmup, dev):
-    ns = argparse.Namespace(no_overlap=False, no_graph=False, no_pipeline=not pipelined, batch=batch, fused_runs=None)
+    ns = argparse.Namespace(no_overlap=False, no_graph=False, no_pipeline=not pipelined, batch=batch, fused_runs=None, dtype="bf16",
+                            level_backward=None, wgrad_chunk=None, teacher_ahead=None, teacher_stages=None, bwd_mode=None)
     data = [synthetic_images(batch, seed=1000 + i)[0].to(dev) for i in range(4)]
     leg = bench.Leg(ns, "bf16", dev, data, 1)
     leg.capture()
