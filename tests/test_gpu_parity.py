@@ -134,8 +134,19 @@ def test_logdet_is_deterministic():
 CASES_1D = ["tab6", "tab63", "tab6_k5_h32", "tab5_cond"]
 
 
+@pytest.fixture
+def tab_layout(request):
+    """resident: weights in LDS for the life of a workgroup, contractions on exact-f32 MFMA (the default where it fits);
+    staged: the per-tile staging on the vector ALUs (what steps wider than 64 features or hidden units fall back to)."""
+    from nf_distillation_amd import capi
+    capi.lib().nfk_tune(capi.TUNE_TAB_RESIDENT, 1 if request.param == "resident" else 0)
+    yield request.param
+    capi.lib().nfk_tune(capi.TUNE_TAB_RESIDENT, 1)
+
+
+@pytest.mark.parametrize("tab_layout", ["resident", "staged"], indirect=True)
 @pytest.mark.parametrize("name", CASES_1D)
-def test_tabular_forward_backward_reverse(name):
+def test_tabular_forward_backward_reverse(name, tab_layout):
     """1-D Glow (BASELINE.json configs 1 and 5 map onto this path: SURVEY.md §0 F1)."""
     g = Golden(name)
     model = build(g.cfg, g.group("sd"))
@@ -178,6 +189,36 @@ def test_tabular_large_batch_round_trip():
         rev = model(z=outs[-1], temperature=1.0, reverse=True)
     assert rel_err(rev[-1].cpu(), x.cpu()) < 1e-4
     assert torch.isfinite(nll).all()
+
+
+def test_tabular_layouts_agree_at_65536_rows():
+    """The two layouts of the 1-D kernels (resident + MFMA, tall tiles / staged + vector ALUs) on the large batch the fixtures
+    do not reach: d = 63 K = 3, 65 536 rows + a ragged tail -- bits/dim 1e-5, every gradient 1e-4 of its largest entry."""
+    from nf_distillation_amd import capi
+    import nf_distillation_amd as nfa
+    cfg = dict(Golden("tab63").cfg)
+    cfg["K"] = 3
+    torch.manual_seed(5)
+    x = torch.randn(65536 + 37, 63, device="cuda")
+    res = {}
+    try:
+        for mode in (1, 0):
+            capi.lib().nfk_tune(capi.TUNE_TAB_RESIDENT, mode)
+            torch.manual_seed(9)
+            m = nfa.create_glow_model(dict(cfg)).cuda()
+            for p in m.parameters():
+                if p.dim() >= 1 and p.numel() > 1 and p.requires_grad:
+                    p.data.add_(0.05 * torch.randn_like(p))
+            _, nll, _ = m(x.clone(), None)
+            nll.mean().backward()
+            torch.cuda.synchronize()
+            res[mode] = (nll.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        capi.lib().nfk_tune(capi.TUNE_TAB_RESIDENT, 1)
+    assert rel_err(res[1][0].cpu(), res[0][0].cpu()) < 1e-5
+    for k, gref in res[0][1].items():
+        if float(gref.abs().max()) > 0:
+            assert rel_err(res[1][1][k].cpu(), gref.cpu()) < 1e-4, (k, rel_err(res[1][1][k].cpu(), gref.cpu()))
 
 
 REVGRAD_CASES = ["tab6_revgrad", "tab63_revgrad", "tab6_k5_h32_revgrad", "tab6_additive_nolu_revgrad",
