@@ -167,12 +167,6 @@ class Leg:
             from nf_distillation_amd.pipeline import AheadPipelinedStep, PipelinedStep, StagedPipelinedStep
             cls = {"ahead": AheadPipelinedStep, "staged": StagedPipelinedStep}.get(kind, PipelinedStep)
             runner = cls(self.step, data[0], strict=True)
-            if getattr(a, "phase_lock", None) is not None:
-                runner.phase_lock = bool(a.phase_lock)
-            if getattr(a, "student_first", None) is not None:
-                runner.student_first = bool(a.student_first)
-            if getattr(a, "teacher_start_layer", None) is not None:   # experiment knob (-1: fork at the start of the call)
-                runner.teacher_starts_after_layer = None if a.teacher_start_layer < 0 else a.teacher_start_layer
             runner.prepare(data[0])   # prime + eager warm-up + capture, before the W warm-up steps
         elif kind == "graph":
             from nf_distillation_amd.training import CapturedStep
@@ -362,13 +356,6 @@ def main():
                     help="experiment knob: the student's bf16 backward -- 0 per-step calls, 1 per level with one launch per step, "
                          "2 with runs of steps in one launch, 3 with the per-level launches on the auxiliary stream (default: the engine's)")
     ap.add_argument("--wgrad-chunk", type=int, default=None, help="experiment knob: engine.level_wgrad_chunk of the student")
-    ap.add_argument("--student-first", type=int, default=None, choices=(0, 1),
-                    help="experiment knob: PipelinedStep.student_first (order in which the two branches' graph nodes are created)")
-    ap.add_argument("--phase-lock", type=int, default=None, choices=(0, 1),
-                    help="experiment knob: PipelinedStep.phase_lock (level-1 phases of the two chains one after the other, their "
-                         "deep-level phases beside each other)")
-    ap.add_argument("--teacher-start-layer", type=int, default=None,
-                    help="experiment knob: student layer after which the pipelined teacher branch is forked (-1: at once)")
     ap.add_argument("--tune", type=int, nargs="*", default=None, metavar="KNOB VALUE",
                     help="experiment knobs: pairs for nfk_tune(knob, value) (include/nfk.h NFK_TUNE_*)")
     ap.add_argument("--bwd-mode", type=int, default=None, help="experiment knob: nfk_step2d_grads.bwd_mode of the student "

@@ -54,7 +54,6 @@ class FlowEngine:
         self._tensor_list = None
         self.grad_hook = None  # callable(layer_index): that layer's parameter grads are final
         self.first_layer_hook = None  # callable(): first layer enqueued (input x may now be reused)
-        self.layer_hooks = {}         # {layer index: callable()}: called once that layer of an encode has been enqueued
         self.fused = True      # bf16 mode: one fused launch per FlowStep forward where the geometry allows
         # hidden split of the fused step on small grids also for passes that keep nothing (a frozen teacher): on the
         # critical path it shortens the step; beside another chain (pipeline.py) it only takes CUs away from that chain
@@ -861,9 +860,6 @@ class _EncodeFn(torch.autograd.Function):
                     if out is not None:
                         cur = out
                 skip_until = r.idx + n
-                for k in range(r.idx, r.idx + n):
-                    if k in eng.layer_hooks:
-                        eng.layer_hooks[k]()
                 continue
             if r.kind == "squeeze":
                 out = torch.empty((B, r.H // 2, r.W // 2, 4 * r.C), device=dev, dtype=torch.float32)
@@ -1012,8 +1008,6 @@ class _EncodeFn(torch.autograd.Function):
             outs.append(out.permute(0, 3, 1, 2) if (keep is None or r.idx in keep) else None)
             if r is st["recs"][0] and eng.first_layer_hook is not None:
                 eng.first_layer_hook()  # the model input has been consumed (and dequantised in place)
-            if r.idx in eng.layer_hooks:
-                eng.layer_hooks[r.idx]()
         if not hints_only:
             ld = flush_ld(ld)
         ctx.saved = saved

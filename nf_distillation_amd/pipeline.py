@@ -28,16 +28,6 @@ import torch
 from .training import DistillationStep, distillation_loss
 
 
-def _last_step_of_first_level(model):
-    """Index of the last layer before the first Split2d (the last FlowStep of level 1); the last layer if there is none."""
-    from .modules import Split2d
-    layers = list(model.flow.layers)
-    for i, l in enumerate(layers):
-        if isinstance(l, Split2d):
-            return i - 1
-    return len(layers) - 1
-
-
 class PipelinedStep:
     def __init__(self, step: DistillationStep, example_x, use_graph=True, warmup=2, with_noise=False, strict=False):
         self.strict = strict    # True: a failed capture raises instead of degrading to eager execution
@@ -72,21 +62,9 @@ class PipelinedStep:
         # of spreading over 256 for 19.8 + 5 us (split + finishing launch); +2 % step throughput.  Alone on the chip (the
         # sequential schedule) the 4-way split of both levels is the faster one and stays the engine's default.
         self.student_split = "frugal"
-        # the student layer after which the teacher's branch is forked; None (default): at the start of the call.  Measured
-        # (bench.py --teacher-start-layer): forking it after the student's first level, so that the two chains' full-chip
-        # level-1 launches do not meet, LOSES 2.6 % (after the second level: 7.5 %) -- the teacher's chain then ends later
-        # than the student's backward can use the freed CUs
-        self.teacher_starts_after_layer = None
-        # Phase lock (experiment, bench.py --phase-lock): the two chains' launches come in two kinds -- level 1 wants every
-        # CU (256 workgroups, one per CU), the deep levels run for long on 64.  Side by side, a 256-workgroup launch beside a
-        # 64-CU run takes two rounds on the 192 free CUs: twice its time.  Locked: student level 1 -> teacher level 1 (each
-        # alone on the chip) -> both deep phases beside each other (64 + 64 CUs) -> the student's level-1 backward.
-        self.phase_lock = False
-        # Order in which the two branches' launches are enqueued (and their graph nodes created).  A replayed hipGraph is fed
-        # to the hardware queues node by node in creation order, at a rate the host sets -- not all at once: with the
-        # teacher's ~45 nodes created first the student's chain, which IS the step's critical path, saw its first kernel
-        # ~0.75 ms after the teacher's (rocprofv3 timeline, profiles/r03_timeline_*.txt).  True: the student's nodes first.
-        self.student_first = False
+        # Tried and dropped, with the measurements (profiles/r02_*, profiles/r03_schedule_experiments.json): forking the teacher's
+        # branch after the student's first or second level (-2.6 % / -7.5 %), a lock-step of the two chains' level-1 phases
+        # (-6 %), creating the student's graph nodes before the teacher's (no change).
 
     # ------------------------------------------------------------------ the two branches
     def _teacher_branch(self):
@@ -136,57 +114,15 @@ class PipelinedStep:
         """both branches up to the end of the backward"""
         main = torch.cuda.current_stream()
         self._handover()   # what the previous call prepared
-        box = {}
-
-        teng = self.step.teacher.flow.engine() if hasattr(self.step.teacher, "flow") else None
-
-        def start_teacher():
-            fork = torch.cuda.Event()
-            fork.record(main)
-            self.side.wait_event(fork)
-            with torch.cuda.stream(self.side):
-                if self.phase_lock and teng is not None:
-                    def l1_done():
-                        box["t_l1"] = torch.cuda.Event()
-                        box["t_l1"].record(self.side)
-                    teng.layer_hooks = {_last_step_of_first_level(self.step.teacher): l1_done}
-                try:
-                    self._teacher_branch()
-                finally:
-                    if teng is not None:
-                        teng.layer_hooks = {}
-                box["join"] = torch.cuda.Event()
-                box["join"].record(self.side)
-            if "t_l1" in box:
-                main.wait_event(box["t_l1"])   # the student's deep levels start when the teacher's level 1 has left the chip
-
-        seng = self.step.student.flow.engine() if hasattr(self.step.student, "flow") else None
-        k = self.teacher_starts_after_layer
-        if self.phase_lock and seng is not None:
-            k = _last_step_of_first_level(self.step.student)
-        if self.student_first:
-            # the teacher's branch still forks from the START of the call (the event is recorded here), but its launches are
-            # ENQUEUED -- and, in a captured graph, created -- after the student's: see student_first in __init__
-            fork0 = torch.cuda.Event()
-            fork0.record(main)
-            out = self._student_fwd_bwd()
-            self.side.wait_event(fork0)
-            with torch.cuda.stream(self.side):
-                self._teacher_branch()
-                box["join"] = torch.cuda.Event()
-                box["join"].record(self.side)
-        elif seng is None or k is None:
-            start_teacher()
-            out = self._student_fwd_bwd()
-        else:
-            seng.layer_hooks = {k: start_teacher}   # experiment: fork the teacher once student layer k has been enqueued
-            try:
-                out = self._student_fwd_bwd()
-            finally:
-                seng.layer_hooks = {}
-            if "join" not in box:
-                start_teacher()
-        main.wait_event(box["join"])
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self.side.wait_event(fork)
+        with torch.cuda.stream(self.side):
+            self._teacher_branch()
+            join = torch.cuda.Event()
+            join.record(self.side)
+        out = self._student_fwd_bwd()
+        main.wait_event(join)
         return out
 
     def _body(self):
