@@ -89,9 +89,14 @@ class PipelinedStep:
             self.t_cur = [torch.empty_like(h) for h in hints]
         torch._foreach_copy_(self.t_next, hints)   # one launch for all hint tensors
 
-    def _student_fwd_bwd(self):
+    def _student_fwd_bwd(self, zero=True, before_loss=None):
+        """zero=False: the caller clears the gradient arena itself (on another stream); before_loss(): called between the
+        student's forward and the loss (the staged pipeline waits there for the hint tensors' hand-over)."""
         st = self.step
-        st.flat.zero_grad()
+        if zero:
+            st.flat.zero_grad()
+        else:
+            st.flat.attach_grads()
         st.reducer.reset()
         seng = st.student.flow.engine() if hasattr(st.student, "flow") else None
         prev = seng.fused_split_training if seng is not None else None
@@ -102,6 +107,8 @@ class PipelinedStep:
         finally:
             if seng is not None:
                 seng.fused_split_training = prev
+        if before_loss is not None:
+            before_loss()
         out = distillation_loss(s_nll, [s_z[i] for i in st.s_idx], self.t_cur, st.w_nll, st.w_kd)
         out["result_loss"].backward()
         return {k: v.detach() for k, v in out.items()}
@@ -434,11 +441,12 @@ class StagedPipelinedStep(PipelinedStep):
             self.hb_a, self.hb_cur = [torch.empty_like(h) for h in hints], [torch.empty_like(h) for h in hints]
         torch._foreach_copy_(self.hb_a, hints)
 
-    def _shift(self, full=True):
+    def _shift(self, full=True, x_done=False):
         """Everything moves one age on: what the student reads first (two multi-tensor copies: the second one's sources are
-        the first one's destinations' sources)."""
+        the first one's destinations' sources).  x_done: the caller has copied the student's input already."""
         if full:
-            torch._foreach_copy_(self.h_cur + self.hb_cur + [self.x_cur, self.za_cur], self.h_b + self.hb_a + [self.xs_b, self.za_a])
+            torch._foreach_copy_(self.h_cur + self.hb_cur + ([] if x_done else [self.x_cur]) + [self.za_cur],
+                                 self.h_b + self.hb_a + ([] if x_done else [self.xs_b]) + [self.za_a])
             self.t_cur = self.h_cur + self.hb_cur
         else:   # priming: no stage-B results yet
             self.za_cur.copy_(self.za_a)
@@ -460,12 +468,36 @@ class StagedPipelinedStep(PipelinedStep):
         return joins
 
     def _body_a(self):
+        """The student's chain is the step: of the hand-over only its input is copied on its stream; the hint tensors move on
+        stage A's stream (the loss waits for them), the gradient arena is cleared on stage B's (the loss's backward waits)."""
         main = torch.cuda.current_stream()
-        self._shift()
-        joins = self._fork_stages(main)
-        out = self._student_fwd_bwd()
-        for ev in joins:
-            main.wait_event(ev)
+        self.x_cur.copy_(self.xs_b)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self.side.wait_event(fork)
+        self.side_b.wait_event(fork)
+        with torch.cuda.stream(self.side):
+            self._shift(x_done=True)
+            shifted = torch.cuda.Event()
+            shifted.record(self.side)
+            self._stage_a()
+            join_a = torch.cuda.Event()
+            join_a.record(self.side)
+        with torch.cuda.stream(self.side_b):
+            self.step.flat.grad.zero_()
+            zeroed = torch.cuda.Event()
+            zeroed.record(self.side_b)
+            self.side_b.wait_event(shifted)
+            self._stage_b()
+            join_b = torch.cuda.Event()
+            join_b.record(self.side_b)
+
+        def hints_ready():
+            main.wait_event(shifted)
+            main.wait_event(zeroed)
+        out = self._student_fwd_bwd(zero=False, before_loss=hints_ready)
+        main.wait_event(join_a)
+        main.wait_event(join_b)
         return out
 
     # ---- public API
