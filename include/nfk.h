@@ -320,6 +320,13 @@ typedef struct nfk_level_bwd {
   int32_t wgrad_chunk, pad_;                     /* > 0 (one launch per step only): the weight-gradient / reduction launches go out
                                                   * for every `wgrad_chunk` steps walked instead of once per call -- on `aux` they
                                                   * then run beside the remaining steps' launches */
+  /* optional: the parameter-side chain (nfk_prep_bwd) of the walked steps -- entry 0 of both arrays = step k_lo, prep_n =
+   * k_hi - k_lo + 1 -- goes out behind the level's reductions on the same stream (on `aux`: under the next level's launches
+   * instead of at the end of the backward).  The caller then leaves these steps out of its final nfk_prep_bwd
+   * (nfk_prep_grad.part == NULL skips a step there). */
+  const nfk_prep_desc *prep_descs;
+  const nfk_prep_grad *prep_grads;
+  int32_t prep_n, prep_dense;
 } nfk_level_bwd;
 int nfk_level_bwd_ok(const nfk_step2d *first);        /* 1: nfk_level2d_bwd covers this geometry */
 int nfk_level_bwd_parts(const nfk_step2d *first);     /* partial (gWf, gcf) slabs per step = workgroups of the step launch */

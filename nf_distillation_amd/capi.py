@@ -77,7 +77,8 @@ class LevelBwd(C.Structure):
                 ("hsave", c_fp), ("hsave_stride", C.c_int64), ("h1save", c_fp), ("h2save", c_fp), ("h_stride", C.c_int64),
                 ("masks", c_fp), ("mask_stride", C.c_int64), ("g_out", c_fp), ("g_ext", c_fp), ("g_ld", c_fp),
                 ("g_x", c_fp), ("ws", c_fp), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("multi", C.c_int32),
-                ("pad_", C.c_int32), ("aux", c_fp), ("wgrad_chunk", C.c_int32), ("pad2_", C.c_int32)]
+                ("pad_", C.c_int32), ("aux", c_fp), ("wgrad_chunk", C.c_int32), ("pad2_", C.c_int32),
+                ("prep_descs", c_fp), ("prep_grads", c_fp), ("prep_n", C.c_int32), ("prep_dense", C.c_int32)]
 
 
 class Step2dPending(C.Structure):

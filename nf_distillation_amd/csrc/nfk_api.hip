@@ -749,6 +749,10 @@ int nfk_level2d_bwd(const nfk_level_bwd* lv, const nfk_step2d* host_steps, void*
     wa.k_lo = lo; wa.k_hi = hi; wa.rows = grid;
     wa.S = level_wgrad_splits(M, s->hidden, L.K3p, L.K1p, hi - lo + 1);
     NFK_TRY(level_wgrad_launch(wa, wst, wst));
+    if (lo == lv->k_lo && lv->prep_n > 0 && lv->prep_descs && lv->prep_grads) {   // behind the walk's last reductions
+      if (lv->prep_n != kh - lv->k_lo + 1) return NFK_ERR_ARG;
+      NFK_TRY(launch_prep_bwd(lv->prep_descs, lv->prep_grads, lv->prep_n, lv->g_ld, B, lv->prep_dense, wst));
+    }
   }
   return NFK_OK;
 }

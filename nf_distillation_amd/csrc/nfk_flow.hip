@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) prep_bwd_kernel(const PrepDesc* __restric
   __shared__ float vec[2 * 256];   // ActNorm bias | e^{logs} of the step (C <= 256)
   const PrepDesc d = descs[blockIdx.x];
   const PrepGrad g = grads[blockIdx.x];
-  if (d.C == 0 || d.C > 256) return;
+  if (d.C == 0 || d.C > 256 || !g.part) return;   // (no partial sums: a step whose chain a level call has run already)
   // the C x C work matrices (and P) live in LDS when six of them fit the 60 KiB the launch provides (C <= 50);
   // wider steps fall back to the step's global scratch
   extern __shared__ __attribute__((aligned(16))) float pb_lds[];
@@ -454,6 +454,7 @@ __global__ void __launch_bounds__(256) prep_bwd_dense_kernel(const PrepDesc* __r
   const PrepDesc d = descs[blockIdx.x];
   if (d.perm_kind != PERM_DENSE) return;
   const PrepGrad g = grads[blockIdx.x];
+  if (!g.part) return;
   const int C = d.C, CC = C * C;
   float* W = d.scratch;
   float* T0 = W + CC;

@@ -1157,6 +1157,18 @@ class _EncodeFn(torch.autograd.Function):
             lv.multi = 1 if eng.level_multi else 0
             lv.aux = eng.aux if (eng.level_wgrad_aux and eng.grad_hook is None) else None
             lv.wgrad_chunk = int(eng.level_wgrad_chunk) if lv.aux else 0
+            # with the auxiliary stream the level's parameter-side chain (nfk_prep_bwd of its steps) follows its reductions
+            # THERE, under the next level's launches, instead of waiting for the end of the backward (where only the first
+            # level's is left: the narrow steps, whose LU chains are the short ones)
+            lpg_dev = None
+            if lv.aux:
+                lpg = [_prep_grad(q, npart) for q in recs[first:first + n]]
+                psig = tuple((d.part, d.nparts, d.g_an_bias, d.g_lower, d.g_weight) for d in lpg)
+                pcache = st.setdefault("level_prep_grads", {})
+                if first not in pcache or pcache[first][0] != psig:
+                    pcache[first] = (psig, capi.struct_array_to_device(lpg, dev))
+                lpg_dev = pcache[first][1]
+                prep_done.update(q.idx for q in recs[first:first + n])
             k_hi = n - 1
             while k_hi >= 0:
                 ext = _ext(i + (n - 1 - k_hi))
@@ -1167,6 +1179,10 @@ class _EncodeFn(torch.autograd.Function):
                 gx = torch.empty((B, r0.H, r0.W, r0.C), device=dev, dtype=torch.float32)
                 lv.g_out, lv.g_ext, lv.g_x = ptr(g_main), ptr(g_e), ptr(gx)
                 lv.k_lo, lv.k_hi = k_lo, k_hi
+                if lpg_dev is not None:
+                    lv.prep_descs = st["prep_dev"].data_ptr() + C.sizeof(capi.PrepDesc) * (r0.prep_i + k_lo)
+                    lv.prep_grads = lpg_dev.data_ptr() + C.sizeof(PrepGrad) * k_lo
+                    lv.prep_n, lv.prep_dense = k_hi - k_lo + 1, int(st["any_dense"])
                 check(lib.nfk_level2d_bwd(C.byref(lv), info["host"], s), "nfk_level2d_bwd")
                 if lv.aux:
                     aux_used.append(True)
@@ -1177,7 +1193,21 @@ class _EncodeFn(torch.autograd.Function):
                 eng.grad_hook(first)   # every layer of the level at once: its gradients are final behind the level's last launch
             return g
 
-        aux_used, keep_alive = [], []
+        def _prep_grad(q, nparts):
+            d = PrepGrad()
+            off, _ = part_off[q.idx]
+            d.part, d.nparts = parts.data_ptr() + 4 * off, nparts
+            an = q.mod.actnorm
+            d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
+            if q.mod.flow_permutation_type == "invconv":
+                ic = q.mod.invconv
+                if ic.LU_decomposed:
+                    d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
+                else:
+                    d.g_weight = ptr(ic.weight.grad)
+            return d
+
+        aux_used, keep_alive, prep_done = [], [], set()
         g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
         rows_in, n_step = 0, 0   # partial rows the previous call left for this step (0: none); steps processed
         skip_to = 0
@@ -1291,24 +1321,16 @@ class _EncodeFn(torch.autograd.Function):
         pg = []
         for r in recs:
             d = PrepGrad()
-            if r.kind == "step":
-                off, nb = part_off[r.idx]
-                d.part, d.nparts = parts.data_ptr() + 4 * off, nparts_used.get(r.idx, nb)
-                an = r.mod.actnorm
-                d.g_an_bias, d.g_an_logs = ptr(an.bias.grad), ptr(an.logs.grad)
-                if r.mod.flow_permutation_type == "invconv":
-                    ic = r.mod.invconv
-                    if ic.LU_decomposed:
-                        d.g_lower, d.g_upper, d.g_log_s = ptr(ic.lower.grad), ptr(ic.upper.grad), ptr(ic.log_s.grad)
-                    else:
-                        d.g_weight = ptr(ic.weight.grad)
+            if r.kind == "step" and r.idx not in prep_done:   # (prep_done: a level call has run this step's chain already)
+                d = _prep_grad(r, nparts_used.get(r.idx, part_off[r.idx][1]))
             if r.kind in ("step", "split"):
                 pg.append(d)
         sig = tuple((d.part, d.nparts, d.g_an_bias, d.g_lower, d.g_weight) for d in pg)
         if st["grad_sig"] != sig:
             st["grad_dev"], st["grad_sig"] = capi.struct_array_to_device(pg, dev), sig
-        check(lib.nfk_prep_bwd(ptr(st["prep_dev"]), ptr(st["grad_dev"]), st["n_prep"], ptr(g_ld), B, st["any_dense"], s),
-              "nfk_prep_bwd")
+        if any(r.kind == "step" and r.idx not in prep_done for r in recs):
+            check(lib.nfk_prep_bwd(ptr(st["prep_dev"]), ptr(st["grad_dev"]), st["n_prep"], ptr(g_ld), B, st["any_dense"], s),
+                  "nfk_prep_bwd")
         ctx.keep = (parts, keep_alive)
         gx = g if ctx.needs_input_grad[1] else None
         if gx is not None and gx.dim() == 4 and recs[0].kind != "squeeze":
