@@ -23,6 +23,8 @@ starts the pipeline and `drain()` trains on the last batch.  Results are bit-ide
 Multi-GPU: as in `training.CapturedStep` the collective is never captured: graph A = both branches up to the end
 of the backward, then the eager bucketed all-reduce of the flat gradient arena, then graph B = clip + Adam.
 """
+import os
+
 import torch
 
 from .training import DistillationStep, distillation_loss
@@ -415,6 +417,241 @@ class StagedPipelinedStep(PipelinedStep):
         self.za_a = self.za_cur = None                   # stage A's output: written (age 0) / read by stage B (age 1)
         self.hb_a = self.hb_cur = None                   # stage B's hint tensors: written (age 1) / read by the student (age 2)
         self.in_flight = 0
+        self.student_first = os.environ.get("NFK_STAGED_STUDENT_FIRST", "1") == "1"   # (see _body_a)
+
+    # ---- the two stages (each on the stream that is current when it is called)
+    def _stage_a(self):
+        st = self.step
+        n_s = self.ns_in if self.ns_in is not None else torch.empty_like(self.x_in).uniform_(0, 1.0 / 256)
+        self.x_in.add_(n_s)
+        self.xs_a.copy_(self.x_in)
+        n_t = self.nt_in if self.nt_in is not None else torch.empty_like(self.x_in).uniform_(0, 1.0 / 256)
+        self.eng_a.fused_split_inference = self.teacher_split
+        with torch.no_grad():
+            outs, _ = self.eng_a.encode(self.x_in, None, 0.0, n_t, keep=self.keep_a, hints_only=True)
+        hints, za = [outs[i] for i in self.keep_a], outs[-1]
+        if self.h_a is None:
+            self.h_a, self.h_b, self.h_cur = ([torch.empty_like(h) for h in hints] for _ in range(3))
+            self.za_a, self.za_cur = torch.empty_like(za), torch.empty_like(za)
+        torch._foreach_copy_(self.h_a + [self.za_a], hints + [za])
+
+    def _stage_b(self):
+        self.eng_b.fused_split_inference = self.teacher_split
+        with torch.no_grad():
+            outs, _ = self.eng_b.encode(self.za_cur, None, 0.0, None, keep=self.keep_b, hints_only=True)
+        hints = [outs[i] for i in self.keep_b]
+        if self.hb_a is None:
+            self.hb_a, self.hb_cur = [torch.empty_like(h) for h in hints], [torch.empty_like(h) for h in hints]
+        torch._foreach_copy_(self.hb_a, hints)
+
+    def _shift(self, full=True, x_done=False):
+        """Everything moves one age on: what the student reads first (two multi-tensor copies: the second one's sources are
+        the first one's destinations' sources).  x_done: the caller has copied the student's input already."""
+        if full:
+            torch._foreach_copy_(self.h_cur + self.hb_cur + ([] if x_done else [self.x_cur]) + [self.za_cur],
+                                 self.h_b + self.hb_a + ([] if x_done else [self.xs_b]) + [self.za_a])
+            self.t_cur = self.h_cur + self.hb_cur
+        else:   # priming: no stage-B results yet
+            self.za_cur.copy_(self.za_a)
+        torch._foreach_copy_(self.h_b + [self.xs_b], self.h_a + [self.xs_a])
+
+    def _fork_stages(self, main, run_a=True, run_b=True):
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for stream, fn, on in ((self.side, self._stage_a, run_a), (self.side_b, self._stage_b, run_b)):
+            if not on:
+                continue
+            stream.wait_event(fork)
+            with torch.cuda.stream(stream):
+                fn()
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                joins.append(ev)
+        return joins
+
+    def _body_a(self):
+        """The student's chain is the step: of the hand-over only its input is copied on its stream; the hint tensors move on
+        stage A's stream (the loss waits for them), the gradient arena is cleared on stage B's (the loss's backward waits).
+        student_first: the student's launches are enqueued -- in a captured graph: its nodes created -- before the stages'.
+        A replayed hipGraph reaches the hardware queues node by node in creation order at a rate the host sets; the stages
+        have slack, the student's chain has none."""
+        main = torch.cuda.current_stream()
+        self.x_cur.copy_(self.xs_b)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self.side.wait_event(fork)
+        self.side_b.wait_event(fork)
+        with torch.cuda.stream(self.side):
+            self._shift(x_done=True)
+            shifted = torch.cuda.Event()
+            shifted.record(self.side)
+        with torch.cuda.stream(self.side_b):
+            self.step.flat.grad.zero_()
+            zeroed = torch.cuda.Event()
+            zeroed.record(self.side_b)
+            self.side_b.wait_event(shifted)
+
+        def hints_ready():
+            main.wait_event(shifted)
+            main.wait_event(zeroed)
+
+        def stages():
+            with torch.cuda.stream(self.side):
+                self._stage_a()
+                join_a = torch.cuda.Event()
+                join_a.record(self.side)
+            with torch.cuda.stream(self.side_b):
+                self._stage_b()
+                join_b = torch.cuda.Event()
+                join_b.record(self.side_b)
+            return join_a, join_b
+        if self.student_first:
+            out = self._student_fwd_bwd(zero=False, before_loss=hints_ready)
+            joins = stages()
+        else:
+            joins = stages()
+            out = self._student_fwd_bwd(zero=False, before_loss=hints_ready)
+        for ev in joins:
+            main.wait_event(ev)
+        return out
+
+    # ---- public API
+    def prime(self, x0, x1=None, noise_s=None, noise_t=None, noise_s1=None, noise_t1=None):
+        """teacher(x0) -> handover -> teacher(x1) in flight.  x1 defaults to x0 (benchmarks that cycle one batch)."""
+        x1 = x0 if x1 is None else x1
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.main):
+            self.ev_h.record(self.main)
+        self._teacher_async(x0, noise_s, noise_t)
+        with torch.cuda.stream(self.main):
+            self._handover_main()
+        self._teacher_async(x1, noise_s1 if noise_s1 is not None else noise_s, noise_t1 if noise_t1 is not None else noise_t)
+        cur.wait_event(self.ev_load)
+        cur.wait_stream(self.main)
+        self.primed = True
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        gt, ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gt, stream=self.side):
+            self._teacher_branch()
+        with torch.cuda.graph(ga, stream=self.main):
+            self.out = self._student_fwd_bwd()
+        with torch.cuda.graph(gb, stream=self.main):
+            self.step.optimize()
+        self.graph_t, self.graph, self.graph_b = gt, ga, gb
+
+    def _iteration(self, x_new, noise_s, noise_t):
+        """student(t) || teacher(t+1) [in flight] -> handover -> teacher(t+2) launched -> all-reduce(t) -> optimiser(t)"""
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        self.side.wait_stream(cur)   # (x_new was produced on the caller's stream)
+        with torch.cuda.stream(self.main):
+            out = self._student()
+            if x_new is not None:
+                self._handover_main()
+        if x_new is not None:
+            self._teacher_async(x_new, noise_s, noise_t)
+            # the caller may free or overwrite x_new / the noise tensors once this call returns: its stream must not run
+            # ahead of the side stream's copy of them (queued behind the handover event)
+            cur.wait_event(self.ev_load)
+        with torch.cuda.stream(self.main):
+            self._finish()
+        cur.wait_stream(self.main)
+        return out
+
+    def training_step(self, x_next, noise_s=None, noise_t=None):
+        if not self.primed:
+            raise RuntimeError("call prime(first_batch, second_batch) first")
+        if self.use_graph and self.graph is None:
+            if self._warm > 0:
+                self._warm -= 1
+            else:
+                # the capture itself consumes nothing: it records the launches of one teacher branch / one student pass /
+                # one optimiser step without running them (the buffers they touch are the static ones)
+                torch.cuda.synchronize()
+                try:
+                    self._capture_guarded()
+                except Exception as exc:  # pragma: no cover - depends on the runtime
+                    if self.strict:
+                        raise
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the pipelined step failed ({exc!r}); running eagerly")
+                    self.use_graph = False
+                    self.graph = self.graph_b = self.graph_t = None
+                    torch.cuda.synchronize()
+        return self._iteration(x_next, noise_s, noise_t)
+
+    def _capture_guarded(self):
+        """Capture must not disturb the values in flight: the teacher's outputs for the next batch sit in t_next / x_stu_next
+        and the batch after it in x_in.  Nothing executes during capture, but the RNG offsets of the captured uniform draws
+        are registered with the graph-safe generator, and zero_grad / the reducer are reset by the replays themselves."""
+        self._capture()
+
+    def prepare(self, x0, noise_s=None, noise_t=None):
+        self.prime(x0, x0, noise_s, noise_t)
+        while self.use_graph and self.graph is None:
+            self.training_step(x0, noise_s, noise_t)
+
+    def drain(self):
+        """Train on the two batches still in flight (no new teacher work); returns the losses of both, oldest first."""
+        first = self._clone_out(self._iteration(None, None, None))
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.main):
+            self._handover_main()
+            second = self._student()
+            self._finish()
+        cur.wait_stream(self.main)
+        self.primed = False
+        return [first, second]
+
+
+class StagedPipelinedStep(PipelinedStep):
+    """The software pipeline with the frozen teacher cut into TWO stages that run beside each other (and beside the student):
+
+        stage A   level 1 of the teacher on batch t+2         (32 launches that each want the whole chip)
+        stage B   the teacher's deeper levels on batch t+1    (two long launches on 64 CUs each: one per level)
+        student   forward / backward / optimiser on batch t
+
+    In `PipelinedStep` the teacher's forward is one chain of ~2 ms that has to fit beside the student's ~2.9 ms every call --
+    it is co-critical: shortening it by 70 us (the hints-only encode) shortened the step by 100 us.  Cut after level 1, its
+    longest stage is 1.1 ms and never on the critical path.  Every call still does one whole teacher forward's work (stage A
+    of one batch, stage B of another), one student forward + backward and one optimiser step, on the same values in the same
+    RNG order: parameters bit-identical to the sequential step (tests/test_gpu_pipeline.py).
+
+    Call pattern as `AheadPipelinedStep`: `prime(x0, x1)`, then `training_step(x_{t+2})` trains on batch t; `drain()` returns the
+    losses of the two batches still in flight.  The stages are two FlowEngines over slices of the teacher's layer list (shared,
+    frozen parameters; hints-only passes: engine.encode(..., keep, hints_only=True))."""
+
+    def __init__(self, step, example_x, use_graph=True, warmup=2, with_noise=False, strict=False):
+        super().__init__(step, example_x, use_graph, warmup, with_noise, strict)
+        from .engine import FlowEngine
+        from .modules import Split2d
+        layers = list(step.teacher.flow.layers)
+        cut = next((i for i, l in enumerate(layers) if isinstance(l, Split2d)), None)
+        if cut is None or getattr(step.teacher, "is_1d", False):
+            raise ValueError("the staged pipeline needs a multi-level image teacher")
+        self.cut = cut                                   # stage A = layers[:cut] (squeeze + level-1 steps), B = the rest
+        teng = step.teacher.flow.engine()
+        self.eng_a, self.eng_b = FlowEngine(layers[:cut]), FlowEngine(layers[cut:])
+        for e in (self.eng_a, self.eng_b):
+            e.set_compute_dtype("bf16" if teng.bf16 else "f32")
+            e.fused, e.fused_runs = teng.fused, teng.fused_runs
+        n = len(layers)
+        self.keep_a = [i for i in step.t_idx if i < cut]
+        self.keep_b = [(i % n) - cut for i in step.t_idx if (i % n) >= cut]
+        self.side_b = torch.cuda.Stream()
+        self.xs_a = torch.empty_like(example_x)          # student input of the batch stage A works on (age 0)
+        self.xs_b = torch.empty_like(example_x)          # ... of the batch stage B works on (age 1); x_cur is age 2
+        self.h_a = self.h_b = self.h_cur = None          # stage A's hint tensors at ages 0 / 1 / 2
+        self.za_a = self.za_cur = None                   # stage A's output: written (age 0) / read by stage B (age 1)
+        self.hb_a = self.hb_cur = None                   # stage B's hint tensors: written (age 1) / read by the student (age 2)
+        self.in_flight = 0
+        self.student_first = os.environ.get("NFK_STAGED_STUDENT_FIRST", "1") == "1"   # (see _body_a)
 
     # ---- the two stages (each on the stream that is current when it is called)
     def _stage_a(self):
