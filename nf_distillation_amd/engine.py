@@ -87,6 +87,8 @@ class FlowEngine:
         self.bwd_mode = capi.BWD_DEFAULT   # nfk_step2d_grads.bwd_mode: how the bf16 backward of a coupling net is launched
         self.defer_fused_wgrad = False   # bf16 fused backward: weight-gradient launches as a chain of their own on `aux`
         self.aux = None        # nfk_aux handle (training.enable_concurrency): auxiliary stream of the weight-gradient GEMMs
+        self.aux_stream = None   # ... and that stream as a torch object (the deferred half of _refresh runs there)
+        self.defer_refresh = os.environ.get("NFK_DEFER_REFRESH", "1") == "1"   # (see _refresh)
         self.bf16 = False      # throughput mode: bf16 operands / fp32 accumulation in the coupling-net convs
 
     # ------------------------------------------------------------------ parameters
@@ -355,8 +357,17 @@ class FlowEngine:
             for rd in step_repack:
                 rd.flags = 0
 
+        # where the per-forward parameter products can be cut in two: everything the FIRST level reads (its steps' channel-mix
+        # matrices and weight fragments) | the rest, which the forward needs only behind the first Split2d (_refresh)
+        first_split = next((q for q in recs if q.kind == "split"), None)
+        refresh_cut = None
+        if first_split is not None and first_split.prep_i > 0 and all(q.kind == "step" for q in recs if q.idx < first_split.idx and q.kind != "squeeze"):
+            n_lvl1 = sum(1 for q in recs if q.kind == "step" and q.idx < first_split.idx)
+            if n_lvl1 == first_split.prep_i:
+                refresh_cut = (first_split.prep_i, 3 * n_lvl1, first_split.idx)
+
         self.state = {
-            "runs": runs, "levels": levels,
+            "runs": runs, "levels": levels, "refresh_cut": refresh_cut, "refresh_event": None,
             "B": B, "recs": recs, "prep_buf": prep_buf, "pack_buf": pack_buf, "keep": keep,
             "prep_dev": capi.struct_array_to_device(prep_descs, device), "n_prep": len(prep_descs),
             "prep_host": prep_descs,
@@ -380,8 +391,15 @@ class FlowEngine:
             self.key = key
         return self.state
 
-    def _refresh(self, st, want_inverse):
-        """Run prep (+ repack) if parameters may have changed since the cached products were made."""
+    def _refresh(self, st, want_inverse, may_defer=False):
+        """Run prep (+ repack) if parameters may have changed since the cached products were made.
+        may_defer (the encode pass): with the auxiliary stream in use (level_wgrad_aux), only what the first level reads is
+        produced on the caller's stream; the rest goes out on the auxiliary stream and the pass waits for it in front of the
+        first Split2d (st["refresh_event"]) -- the launch sits at the head of the training step's critical chain, and most of
+        its time is the wide steps' LU products and weight fragments."""
+        if st.get("refresh_event") is not None:   # (a pass that ended before its wait: never leave the products half-made)
+            torch.cuda.current_stream().wait_event(st["refresh_event"])
+            st["refresh_event"] = None
         trainable = any(p.requires_grad for p in self.params())
         ver = self._version()
         # row-major weight copies: read by the reverse pass and by every path but the fused forward / fused backward
@@ -394,8 +412,24 @@ class FlowEngine:
         lib, s = capi.lib(), capi.stream()
         if self.bf16:   # one launch: prep of every step, the Split2d convs (f32) and the coupling nets' convs (bf16)
             rp = st["step_repack_dev"] if want_plain else st["step_repack_frag_dev"]
-            check(lib.nfk_prep_repack(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, ptr(st["repack_dev"]),
-                                      st["n_repack"], ptr(rp), st["n_step_repack"], s), "nfk_prep_repack")
+            cut = st["refresh_cut"]
+            if (may_defer and self.defer_refresh and cut is not None and not want_inverse and trainable and self.aux_stream is not None and
+                    self.aux is not None and self.level_wgrad_aux):
+                pA, rA, _ = cut
+                cur = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(cur)
+                self.aux_stream.wait_event(fork)
+                with torch.cuda.stream(self.aux_stream):
+                    check(lib.nfk_prep_repack(ptr(st["prep_dev"]) + C.sizeof(PrepDesc) * pA, st["n_prep"] - pA, 0,
+                                              ptr(st["repack_dev"]), st["n_repack"], ptr(rp) + C.sizeof(RepackDesc) * rA,
+                                              st["n_step_repack"] - rA, capi.stream()), "nfk_prep_repack (deferred part)")
+                    st["refresh_event"] = torch.cuda.Event()
+                    st["refresh_event"].record(self.aux_stream)
+                check(lib.nfk_prep_repack(ptr(st["prep_dev"]), pA, 0, None, 0, ptr(rp), rA, s), "nfk_prep_repack (first level)")
+            else:
+                check(lib.nfk_prep_repack(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, ptr(st["repack_dev"]),
+                                          st["n_repack"], ptr(rp), st["n_step_repack"], s), "nfk_prep_repack")
             st["has_plain"] = want_plain
         else:
             check(lib.nfk_prep(ptr(st["prep_dev"]), st["n_prep"], 1 if want_inverse else 0, s), "nfk_prep")
@@ -752,7 +786,7 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, x, logdet, noise, y_onehot, keep_and_mode, *params):
         st = eng._ensure(x)
-        eng._refresh(st, False)
+        eng._refresh(st, False, may_defer=True)
         lib, s = capi.lib(), capi.stream()
         B, dev = x.shape[0], x.device
         keep, grad_mode, hints_only = keep_and_mode
@@ -804,6 +838,9 @@ class _EncodeFn(torch.autograd.Function):
         for r in st["recs"]:
             if r.idx < skip_until:
                 continue   # part of a run of steps that one launch has already walked
+            if st["refresh_event"] is not None and r.idx >= st["refresh_cut"][2]:
+                torch.cuda.current_stream().wait_event(st["refresh_event"])   # the deferred half of _refresh
+                st["refresh_event"] = None
             if r.kind == "step" and use_runs and r.idx in st["runs"] and run is None:
                 # ---- a whole level's FlowSteps in ONE launch (whole-image pixel tiles: z stays in LDS between the steps)
                 info = st["runs"][r.idx]

@@ -243,6 +243,7 @@ class DistillationStep:
         eng = self.student.flow.engine() if hasattr(self.student, "flow") else None
         if eng is not None:
             eng.aux = self._aux_handle if on else None
+            eng.aux_stream = self._aux if on else None
 
     def _cond(self, y_onehot):
         """pl_module.py:216-243: y goes to the models iff params["student"]["y_condition"]."""
