@@ -954,17 +954,25 @@ struct LdMulti {
   int nsteps[NFK_LD_MAX_PARTS], tiles[NFK_LD_MAX_PARTS];
   int n;
 };
-__global__ void ld_finish_multi_kernel(const float* __restrict__ ld_in, LdMulti m, int B, float* __restrict__ ld_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per sample: the lanes fetch 64 partials at once, then they are added in the SAME order as the one-thread loop did
+// (v += partial 0, 1, 2, ...: bit-identical) by reading the lanes in turn -- the loop was a chain of ~50 dependent loads per
+// sample (13 us on the training step's critical chain, between the forward and the loss).
+__global__ void __launch_bounds__(64) ld_finish_multi_kernel(const float* __restrict__ ld_in, LdMulti m, int B,
+                                                              float* __restrict__ ld_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   float v = ld_in[b];
   for (int k = 0; k < m.n; ++k) {
     const float* __restrict__ p = m.part[k];
-    const int tps = m.tiles[k];
-    for (int st = 0; st < m.nsteps[k]; ++st)
-      for (int t = 0; t < tps; ++t) v += p[((long)st * B + b) * tps + t];
+    const int tps = m.tiles[k], total = m.nsteps[k] * tps;
+    for (int base = 0; base < total; base += 64) {
+      const int j = base + lane, st = j / tps, t = j - st * tps;
+      const float x = j < total ? p[((long)st * B + b) * tps + t] : 0.f;
+      const int cnt = total - base < 64 ? total - base : 64;
+      for (int i = 0; i < cnt; ++i) v += __shfl(x, i, 64);
+    }
   }
-  ld_out[b] = v;
+  if (lane == 0) ld_out[b] = v;
 }
 
 static unsigned long long* g_stamps = nullptr;   // diagnostic only (nfk_fused_set_stamps)
@@ -1034,8 +1042,7 @@ int nfk_ld_finish_multi(const float* ld_in, const nfk_ld_parts* parts, int n, in
   LdMulti m{};
   m.n = n;
   for (int k = 0; k < n; ++k) { m.part[k] = parts[k].part; m.nsteps[k] = parts[k].nsteps; m.tiles[k] = parts[k].tiles; }
-  hipLaunchKernelGGL(ld_finish_multi_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ld_in, m,
-                     B, ld_out);
+  hipLaunchKernelGGL(ld_finish_multi_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ld_in, m, B, ld_out);
   NFK_LAUNCH_CHECK();
   return NFK_OK;
 }

@@ -56,6 +56,7 @@ class PipelinedStep:
         self.graph = self.graph_b = None
         self.out, self._warm = None, warmup
         self.primed = False
+        self._one = None
         # The teacher's chain runs BESIDE the student's and has slack: of its deep-level fused steps only those that would
         # fill fewer than 32 CUs are split over more workgroups (level 3: 16 -> 64); level 2 stays on its 64 CUs instead
         # of taking all 256 from the student's chain (+3.4 % step throughput against splitting both).
@@ -112,7 +113,9 @@ class PipelinedStep:
         if before_loss is not None:
             before_loss()
         out = distillation_loss(s_nll, [s_z[i] for i in st.s_idx], self.t_cur, st.w_nll, st.w_kd)
-        out["result_loss"].backward()
+        if self._one is None:
+            self._one = torch.ones((), device=out["result_loss"].device, dtype=out["result_loss"].dtype)
+        out["result_loss"].backward(self._one)   # (the seed: a resident 1 instead of a fill launch per step)
         return {k: v.detach() for k, v in out.items()}
 
     def _handover(self):
