@@ -54,7 +54,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec)
 GFLOP_PER_IMAGE = 14.04  # teacher fwd (8.023) + 3 x student fwd (2.006) per distillation step
-PMC_PROFILE = "r03_a_pmc_traffic_bf16.json"   # profiles/: FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
+PMC_PROFILE = "r03_b_pmc_traffic_bf16.json"   # profiles/: FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
 
 
 def cifar_cfg(K):
