@@ -1206,6 +1206,12 @@ class _EncodeFn(torch.autograd.Function):
                     pcache[first] = (psig, capi.struct_array_to_device(lpg, dev))
                 lpg_dev = pcache[first][1]
                 prep_done.update(q.idx for q in recs[first:first + n])
+                if first == min(st["levels"]) and not deferred:
+                    # the level walked LAST: its weight gradients (the longest launch of the backward) have nothing but the
+                    # optimiser behind them, and its parameter-side chain does not read them -- that chain goes out on the
+                    # caller's stream, beside them, instead of behind them
+                    last_prep.append((st["prep_dev"].data_ptr() + C.sizeof(capi.PrepDesc) * r0.prep_i, lpg_dev, n))
+                    lpg_dev = None
             k_hi = n - 1
             while k_hi >= 0:
                 ext = _ext(i + (n - 1 - k_hi))
@@ -1244,7 +1250,7 @@ class _EncodeFn(torch.autograd.Function):
                     d.g_weight = ptr(ic.weight.grad)
             return d
 
-        aux_used, keep_alive, prep_done = [], [], set()
+        aux_used, keep_alive, prep_done, last_prep = [], [], set(), []
         g = None  # grad wrt the current layer's OUTPUT coming from downstream (NHWC)
         rows_in, n_step = 0, 0   # partial rows the previous call left for this step (0: none); steps processed
         skip_to = 0
@@ -1352,6 +1358,8 @@ class _EncodeFn(torch.autograd.Function):
 
         if pend is not None:
             check(lib.nfk_step2d_pending_flush(C.byref(pend), s), "nfk_step2d_pending_flush")
+        for pd_, pg_, n_ in last_prep:
+            check(lib.nfk_prep_bwd(pd_, pg_.data_ptr(), n_, ptr(g_ld), B, st["any_dense"], s), "nfk_prep_bwd (last level)")
         if deferred or aux_used:
             check(lib.nfk_aux_join(eng.aux, s), "nfk_aux_join")
         # parameter-side chain for all steps in one launch
