@@ -195,6 +195,10 @@ class Leg:
         self.fallbacks = []
         for kind in order:
             try:
+                if kind == "ahead":
+                    # three graphs on two streams: with the auxiliary-stream branches inside the student's graph as well the
+                    # graphs run one after the other (12.5 k images/s on one GPU instead of 18.2 k, profiles/r03_schedule_experiments.json)
+                    self.student.flow.engine().level_wgrad_aux = False
                 self.runner = self._build_runner(kind)
                 self.kind = kind
                 break
